@@ -1,0 +1,111 @@
+"""Synthetic inputs for the hot path: camera rig, projection matrices, pyramid geometry.
+
+Everything here is derived from first principles (a pin-hole rig description), not
+copied from the reference; tests/golden/make_golden.py checks that the derived
+LIDAR2IMG matrices agree with the constants the reference's closed-loop agent carries
+(bench2drive/leaderboard/team_code/hipad_b2d_agent.py:39-67) and that the test-time
+resize/crop matrix agrees with datasets/bench2drive_dataset.py:732-741 composed as in
+datasets/pipelines/augment.py:27.
+"""
+import math
+
+import numpy as np
+
+# Bench2Drive sensor rig in the ego frame (x forward, y right, z up), metres / degrees.
+# (name, x, y, z, yaw_deg (positive = to the right), horizontal fov_deg)
+B2D_RIG = (
+    ("CAM_FRONT", 0.80, 0.0, 1.60, 0.0, 70.0),
+    ("CAM_FRONT_LEFT", 0.27, -0.55, 1.60, -55.0, 70.0),
+    ("CAM_FRONT_RIGHT", 0.27, 0.55, 1.60, 55.0, 70.0),
+    ("CAM_BACK", -2.00, 0.0, 1.60, 180.0, 110.0),
+    ("CAM_BACK_LEFT", -0.32, -0.55, 1.60, -110.0, 70.0),
+    ("CAM_BACK_RIGHT", -0.32, 0.55, 1.60, 110.0, 70.0),
+)
+B2D_LIDAR_IN_EGO = (-0.39, 0.0, 1.84)
+B2D_IMAGE_WH = (1600, 900)
+
+
+def bench2drive_lidar2img():
+    """(6,4,4) float64 lidar->image matrices of the Bench2Drive rig.
+
+    Lidar frame: x right, y forward, z up (origin at the lidar).  Camera frame: x right,
+    y down, z along the optical axis.
+    """
+    W, H = B2D_IMAGE_WH
+    mats = []
+    for _, ex, ey, ez, yaw, fov in B2D_RIG:
+        psi = math.radians(-yaw)  # rotation about z, positive = to the left
+        # camera centre in the lidar frame
+        cx_l = ey - B2D_LIDAR_IN_EGO[1]
+        cy_l = ex - B2D_LIDAR_IN_EGO[0]
+        cz_l = ez - B2D_LIDAR_IN_EGO[2]
+        right = np.array([math.cos(psi), math.sin(psi), 0.0])
+        down = np.array([0.0, 0.0, -1.0])
+        fwd = np.array([-math.sin(psi), math.cos(psi), 0.0])
+        R = np.stack([right, down, fwd])
+        c = np.array([cx_l, cy_l, cz_l])
+        l2c = np.eye(4)
+        l2c[:3, :3] = R
+        l2c[:3, 3] = -R @ c
+        f = (W / 2.0) / math.tan(math.radians(fov) / 2.0)
+        K = np.eye(4)
+        K[0, 0] = K[1, 1] = f
+        K[0, 2] = W / 2.0
+        K[1, 2] = H / 2.0
+        mats.append(K @ l2c)
+    return np.stack(mats)
+
+
+def test_time_aug_matrix(final_hw=(256, 704), src_hw=(900, 1600), bot_pct_lim=(0.0, 0.0)):
+    """4x4 image-space matrix of the deterministic test-time resize + crop."""
+    fH, fW = final_hw
+    H, W = src_hw
+    resize = max(fH / H, fW / W)
+    newW, newH = int(W * resize), int(H * resize)
+    crop_h = int((1 - float(np.mean(bot_pct_lim))) * newH) - fH
+    crop_w = int(max(0, newW - fW) / 2)
+    m = np.eye(4)
+    m[0, 0] = m[1, 1] = resize
+    m[0, 3] = -crop_w
+    m[1, 3] = -crop_h
+    return m
+
+
+def projection_mats(final_hw=(256, 704), bs=1, dtype=np.float32):
+    """(bs,6,4,4) projection_mat and (bs,6,2) image_wh as the data pipeline would emit."""
+    m = test_time_aug_matrix(final_hw) @ bench2drive_lidar2img()
+    pm = np.broadcast_to(m[None], (bs,) + m.shape).astype(dtype).copy()
+    wh = np.broadcast_to(np.array([final_hw[1], final_hw[0]], dtype)[None, None], (bs, 6, 2)).copy()
+    return pm, wh
+
+
+def pyramid_shapes(final_hw=(256, 704), strides=(4, 8, 16, 32)):
+    """[(h,w)] per level of the FPN pyramid for an input of final_hw (ceil division like conv stride)."""
+    H, W = final_hw
+    return [(-(-H // s), -(-W // s)) for s in strides]
+
+
+def pyramid_tables(final_hw=(256, 704), strides=(4, 8, 16, 32), num_cams=6):
+    """spatial_shape (cams,L,2) int32 [h,w] and scale_start_index (cams,L) int32, camera-major."""
+    shapes = pyramid_shapes(final_hw, strides)
+    ss = np.array([shapes] * num_cams, np.int32)
+    sizes = (ss[..., 0] * ss[..., 1]).reshape(-1)
+    start = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int32).reshape(num_cams, len(shapes))
+    return ss, start, int(sizes.sum())
+
+
+def ego_motion(step, dx=1.0, dyaw_deg=1.0):
+    """T_global (lidar->global) of frame `step`: planar motion, dx metres forward and dyaw per step."""
+    yaw = math.radians(dyaw_deg) * step
+    T = np.eye(4)
+    T[0, 0] = math.cos(yaw)
+    T[0, 1] = -math.sin(yaw)
+    T[1, 0] = math.sin(yaw)
+    T[1, 1] = math.cos(yaw)
+    # integrate a gentle arc: position advances along the heading (lidar y is forward)
+    pos = np.zeros(2)
+    for k in range(step):
+        yk = math.radians(dyaw_deg) * k
+        pos += dx * np.array([-math.sin(yk), math.cos(yk)])
+    T[0, 3], T[1, 3] = pos
+    return T

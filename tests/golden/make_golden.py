@@ -1,0 +1,292 @@
+"""Generate the golden fixtures in tests/golden/*.npz by RUNNING THE REFERENCE'S OWN PYTHON.
+
+BUILD CONTAINER ONLY (needs /root/reference; the GPU box has neither it nor this need:
+the fixtures are committed).  Usage:
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [--only NAME]
+
+What runs here is the reference's code, imported from where it lies through
+tests/golden/_ref_shim.py (third-party names only are stubbed):
+  * ops.feature_maps_format                      (ops/__init__.py:33-103)
+  * DeformableFeatureAggregation.project_points  (models/blocks.py:216-225)
+  * ...feature_sampling / multi_view_level_fusion (models/blocks.py:227-264), the
+    reference's CPU fallback for the CUDA op, with the CUDA kernel's border rule
+    (sample kept iff 0<x<1 and 0<y<1, deformable_aggregation_cuda.cu:168-171) applied as
+    a mask -- SURVEY.md section 8c's oracle definition; gradients from torch autograd
+  * ..._get_weights, forward                      (models/blocks.py:124-214)
+  * SparseBox3DKeyPointsGenerator (models/det/blocks.py:159-224),
+    SparsePoint3DKeyPointsGenerator (models/map/blocks.py:137-225)
+Only data (inputs, parameters drawn from a seed, outputs) is stored.
+"""
+import argparse
+import os
+import re
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import _ref_shim as S  # noqa: E402
+
+S.install()
+ref_ops = S.ref_import("ops")
+ref_blocks = S.ref_import("models.blocks")
+ref_det = S.ref_import("models.det.blocks")
+ref_map = S.ref_import("models.map.blocks")
+DFA = ref_blocks.DeformableFeatureAggregation
+
+import hipad_amd.synthetic as syn  # noqa: E402
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB)  keys={sorted(out)}")
+
+
+# ----------------------------------------------------------------------------------------
+# the reference fallback, driven with explicit 2-D locations
+# ----------------------------------------------------------------------------------------
+def ref_daf(col_feats, spatial_shape, scale_start_index, loc, weights, num_groups):
+    """Reference CPU path on the formatted triple.
+
+    loc (bs,A,P,cams,2), weights (bs,A,P,cams,L,G) -- the CUDA op's argument layout
+    (ops/src/deformable_aggregation.cpp:23-29).  Returns out (bs,A,C).
+    """
+    bs, A, P, cams = loc.shape[:4]
+    # formatted triple -> per-level (bs,cams,C,h,w) maps, by the reference's own inverse
+    groups = ref_ops.feature_maps_format([col_feats, spatial_shape, scale_start_index], inverse=True)
+    assert len(groups) == 1, "fixtures use one camera group"
+    level_maps = groups[0]
+    L = len(level_maps)
+    C = col_feats.shape[-1]
+
+    # feature_sampling() calls DeformableFeatureAggregation.project_points(key_points, M, wh)
+    # and expects (bs,cams,A,P,2); hand it our locations instead of projecting.
+    loc_cam_major = loc.permute(0, 3, 1, 2, 4)
+    orig = DFA.project_points
+    DFA.project_points = staticmethod(lambda kp, pm, wh=None: loc_cam_major)
+    try:
+        dummy_kp = loc.new_zeros(bs, A, P, 3)
+        feats = DFA.feature_sampling(level_maps, dummy_kp, None, None)  # (bs,A,cams,L,P,C)
+    finally:
+        DFA.project_points = staticmethod(orig)
+    # CUDA border rule as a mask over (bs,A,P,cam)
+    m = ((loc[..., 0] > 0) & (loc[..., 0] < 1) & (loc[..., 1] > 0) & (loc[..., 1] < 1)).to(feats.dtype)
+    feats = feats * m.permute(0, 1, 3, 2)[:, :, :, None, :, None]
+    holder = type("H", (), {})()
+    holder.num_groups, holder.group_dims = num_groups, C // num_groups
+    holder.num_pts, holder.embed_dims = P, C
+    w_ref = weights.permute(0, 1, 3, 4, 2, 5)  # (bs,A,cams,L,P,G)
+    fused = DFA.multi_view_level_fusion(holder, feats, w_ref)  # (bs,A,P,C)
+    return fused.sum(dim=2)
+
+
+def tables(shapes, cams):
+    ss = torch.tensor([shapes] * cams, dtype=torch.int64)
+    sizes = (ss[..., 0] * ss[..., 1]).flatten()
+    start = torch.cat([torch.zeros(1, dtype=torch.int64), sizes.cumsum(0)[:-1]]).reshape(cams, -1)
+    return ss, start, int(sizes.sum())
+
+
+def special_locs(loc, shapes):
+    """Plant the border cases the kernel and grid_sample disagree on / edge cases."""
+    flat = loc.view(-1, 2)
+    h, w = shapes[0]
+    cases = [
+        (0.0, 0.5), (1.0, 0.5), (0.5, 0.0), (0.5, 1.0),            # exactly on the rim: dropped
+        (-0.25 / w, 0.5), (1 + 0.25 / w, 0.5),                    # the sliver grid_sample keeps
+        (0.5, -0.25 / h), (0.5, 1 + 0.25 / h),
+        (0.25 / w, 0.25 / h), (1 - 0.25 / w, 1 - 0.25 / h),       # inside, corners fall off the map
+        (0.5 / w, 0.5 / h), ((w - 0.5) / w, (h - 0.5) / h),       # pixel centres of the rim pixels
+        (1e-7, 0.3), (0.3, 1 - 1e-7),
+        (-3.0, 0.4), (0.4, 7.5), (1e6, -1e6),
+    ]
+    for i, (x, y) in enumerate(cases):
+        flat[i * 3 % flat.shape[0]] = torch.tensor([x, y])
+    return loc
+
+
+def gen_daf_case(name, shapes, cams, bs, A, P, C, G, seed, lo=-0.2, hi=1.2):
+    g = torch.Generator().manual_seed(seed)
+    ss, start, F = tables(shapes, cams)
+    feat = torch.randn(bs, F, C, generator=g)
+    loc = torch.rand(bs, A, P, cams, 2, generator=g) * (hi - lo) + lo
+    loc = special_locs(loc, shapes)
+    w = torch.softmax(torch.randn(bs, A, P * cams * len(shapes), G, generator=g), dim=2)
+    w = w.reshape(bs, A, P, cams, len(shapes), G).contiguous()
+    gout = torch.randn(bs, A, C, generator=g)
+    feat.requires_grad_(True)
+    loc.requires_grad_(True)
+    w.requires_grad_(True)
+    out = ref_daf(feat, ss, start, loc, w, G)
+    out.backward(gout)
+    save(name, feat=feat, spatial_shape=ss, scale_start_index=start, loc=loc, weights=w,
+         out=out, grad_out=gout, grad_feat=feat.grad, grad_loc=loc.grad, grad_weights=w.grad)
+
+
+def gen_daf():
+    # BASELINE.json configs[0]: 1 cam, 1 level, 32x32 feat, 16 queries x 4 points
+    gen_daf_case("daf_unit", [(32, 32)], cams=1, bs=1, A=16, P=4, C=256, G=8, seed=0)
+    # 6 cams x 4 levels miniature pyramid (exercises scale_start_index / spatial_shape), bs=2
+    gen_daf_case("daf_multicam", [(4, 11), (2, 6), (1, 3), (1, 2)], cams=6, bs=2, A=12, P=5, C=256, G=8, seed=1)
+    # odd channel/group split and ragged sizes (generic code path)
+    gen_daf_case("daf_ragged", [(5, 7), (3, 4)], cams=3, bs=1, A=7, P=3, C=96, G=4, seed=2)
+
+
+# ----------------------------------------------------------------------------------------
+def gen_format():
+    g = torch.Generator().manual_seed(3)
+    out = {}
+    # data case: small pyramid, 2 samples, 6 cams, 8 channels
+    shapes = [(6, 10), (3, 5), (2, 3), (1, 2)]
+    maps = [torch.randn(2, 6, 8, h, w, generator=g) for h, w in shapes]
+    col, ss, start = ref_ops.feature_maps_format(maps)
+    back = ref_ops.feature_maps_format([col, ss, start], inverse=True)
+    assert len(back) == 1 and all(torch.equal(a, b) for a, b in zip(back[0], maps))
+    for i, m in enumerate(maps):
+        out[f"small_map{i}"] = m
+    out.update(small_col=col, small_spatial_shape=ss, small_scale_start_index=start)
+    # index tables at the two real input sizes (data-free: channel dim 1, zeros)
+    for tag, hw in (("704x256", (256, 704)), ("640x352", (352, 640))):
+        shp = syn.pyramid_shapes(hw)
+        maps = [torch.zeros(1, 6, 1, h, w) for h, w in shp]
+        col, ss, start = ref_ops.feature_maps_format(maps)
+        out[f"{tag}_spatial_shape"] = ss
+        out[f"{tag}_scale_start_index"] = start
+        out[f"{tag}_num_feat"] = np.array(col.shape[1])
+    save("feature_maps_format", **out)
+
+
+# ----------------------------------------------------------------------------------------
+def ref_lidar2img_from_text():
+    """Read the numeric LIDAR2IMG constants from the agent file's text (data, not code)."""
+    txt = open(os.path.join(S.REF, "bench2drive/leaderboard/team_code/hipad_b2d_agent.py")).read()
+    body = txt[txt.index("LIDAR2IMG = {"): txt.index("LIDAR2CAM = {")]
+    nums = [float(x) for x in re.findall(r"[-+]?\d+\.\d+e[-+]\d+", body)]
+    return np.array(nums).reshape(6, 4, 4)
+
+
+def gen_project():
+    ref_l2i = ref_lidar2img_from_text()
+    mine = syn.bench2drive_lidar2img()
+    assert np.allclose(mine, ref_l2i, rtol=1e-6, atol=1e-6), np.abs(mine - ref_l2i).max()
+    out = {}
+    g = torch.Generator().manual_seed(4)
+    for tag, hw in (("704x256", (256, 704)), ("640x352", (352, 640))):
+        pm, wh = syn.projection_mats(hw, bs=2)
+        pm, wh = torch.from_numpy(pm), torch.from_numpy(wh)
+        # points all around the car, incl. behind each camera (clamp path) and on the axis
+        kp = (torch.rand(2, 40, 7, 3, generator=g) - 0.5) * torch.tensor([60.0, 120.0, 8.0])
+        kp[0, 0, 0] = torch.tensor([0.0, 1.19, -0.24])  # exactly at the front camera centre
+        kp[0, 1, 0] = torch.tensor([0.0, 0.0, 0.0])
+        p2d = DFA.project_points(kp, pm, wh)  # (bs,cams,A,P,2)
+        out[f"{tag}_projection_mat"] = pm
+        out[f"{tag}_image_wh"] = wh
+        out[f"{tag}_key_points"] = kp
+        out[f"{tag}_points_2d"] = p2d
+    save("project_points", **out)
+
+
+# ----------------------------------------------------------------------------------------
+def state(mod):
+    return {k: v.detach().clone() for k, v in mod.state_dict().items()}
+
+
+DET_FIX_SCALE = [[0, 0, 0], [0.45, 0, 0], [-0.45, 0, 0], [0, 0.45, 0], [0, -0.45, 0], [0, 0, 0.45], [0, 0, -0.45]]
+
+
+def cfg_text():
+    return open(os.path.join(S.REF, "projects/configs/hipad_b2d_stage2.py")).read()
+
+
+def dfa_cfgs():
+    """The four `*_deformable` config dicts of hipad_b2d_stage2.py, evaluated from its text."""
+    txt = cfg_text().replace('"/opt/data/private/project/HiP-AD"', repr(S.REF))
+    ns = {}
+    exec(compile(txt, "hipad_b2d_stage2.py", "exec"), ns)
+    head = ns["model"]["head"] if "head" in ns["model"] else None
+    od = None
+    for k, v in ns["model"].items():
+        if isinstance(v, dict) and "onedecoder_head" in v:
+            od = v["onedecoder_head"]
+    if od is None:
+        od = head["onedecoder_head"]
+    return {k: od[f"{k}_deformable"] for k in ("det", "map", "plan", "ego")}, od, ns
+
+
+def gen_keypoints_and_dfa():
+    import copy
+    from seeded import seeded, checksum, fill_parameters
+    cfgs, od, ns = dfa_cfgs()
+    hw = (256, 704)
+    shapes = syn.pyramid_shapes(hw)
+    # a coarse pyramid keeps the run small: same 6 cams / 4 levels, 1/4 resolution
+    shapes_small = [(max(1, h // 4), max(1, w // 4)) for h, w in shapes]
+    pm, wh = syn.projection_mats(hw, bs=1)
+    pm, wh = torch.from_numpy(pm), torch.from_numpy(wh)
+    det_anchor = torch.from_numpy(np.load(os.path.join(S.REF, "data/kmeans/b2d_det_900.npy"))).float()
+    map_anchor = torch.from_numpy(np.load(os.path.join(S.REF, "data/kmeans/b2d_map_100.npy"))).float()
+    plan_anchor = torch.from_numpy(np.load(os.path.join(S.REF, "data/kmeans/b2d_plan_spat_6x8_2m.npy"))).float()
+    anchors = {
+        "det": det_anchor[None, ::23][:, :24],                          # (1,24,11)
+        "map": map_anchor.reshape(100, -1)[None, ::9][:, :4],           # (1,4,40)
+        "plan": plan_anchor.reshape(48, -1)[None, ::7][:, :6],          # (1,6,12)
+        "ego": torch.tensor([[[0, 0.5, -1.84 + 0.78, np.log(1.9), np.log(4.9), np.log(1.6), 1, 0, 0, 0, 0]]]).float(),
+    }
+    maps = [seeded((1, 6, 256, h, w), 700 + i) for i, (h, w) in enumerate(shapes_small)]
+    col, ss, start = ref_ops.feature_maps_format(maps)
+    out = dict(level_shapes=np.array(shapes_small), col_feats_checksum=checksum(col), spatial_shape=ss,
+               scale_start_index=start, projection_mat=pm, image_wh=wh)
+
+    def patched_daf(col_feats, spatial_shape, scale_start_index, points_2d, weights):
+        return ref_daf(col_feats, spatial_shape, scale_start_index, points_2d, weights, weights.shape[-1])
+
+    ref_blocks.DAF = patched_daf
+    for mi, (name, cfg) in enumerate(cfgs.items()):
+        cfg = copy.deepcopy(cfg)
+        out[f"{name}_cfg_repr"] = np.array(repr(cfg))
+        cfg.pop("type")
+        mod = DFA(**cfg)
+        # the reference zero-inits weights_fc (uniform softmax); draw seeded params instead so
+        # the fixture exercises the whole expression
+        out[f"{name}_param_checksum"] = fill_parameters(mod, 1000 * (mi + 1))
+        mod.eval()
+        anchor = anchors[name]
+        A = anchor.shape[1]
+        inst = seeded((1, A, 256), 9000 + mi)
+        emb = seeded((1, A, 256), 9100 + mi)
+        metas = {"projection_mat": pm, "image_wh": wh}
+        with torch.no_grad():
+            kps = mod.kps_generator(anchor, emb, inst)
+            wts = mod._get_weights(inst, emb, metas)
+            y = mod(inst, anchor, emb, [col, ss, start], metas)
+        print(name, "num_pts", mod.num_pts, "kps", tuple(kps.shape), "weights", tuple(wts.shape), "out", tuple(y.shape))
+        out[f"{name}_anchor"] = anchor
+        out[f"{name}_key_points"] = kps
+        out[f"{name}_weights"] = wts
+        out[f"{name}_output"] = y
+        out[f"{name}_param_names"] = np.array([k for k, p in mod.named_parameters() if p.requires_grad])
+    save("dfa_modules", **out)
+
+
+GENS = {"daf": gen_daf, "format": gen_format, "project": gen_project, "dfa": gen_keypoints_and_dfa}
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None, choices=sorted(GENS))
+    a = ap.parse_args()
+    torch.set_num_threads(8)
+    for k, fn in GENS.items():
+        if a.only in (None, k):
+            fn()
