@@ -1,0 +1,237 @@
+#!/usr/bin/env python
+"""bench.py -- frames/s of the HiP-AD hot path on MI355X (contract: see the task brief).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+(one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+
+A "step" = one pass of the hot path over one synthetic frame (6 cameras, 704x256).
+Workloads
+  daf_stage2   the aggregation path of one stage-2 frame: for each of the 6 decoder layers the
+               four deformable-aggregation calls (det 900x13, map 100x300, plan 480x90, ego 1x13
+               key points; 6 cams x 4 levels x 8 groups; C=256 fp32) forward AND backward on the
+               89 760-position pyramid.  This is the hand-written-kernel part of the frame; the
+               rest of the model is not in this number (config.workload says so).
+Inputs are resident in HBM before the timed region.  `roofline` is for the dominant kernel, timed
+live with HIP events on the launch stream; `cpu_baseline` times the CPU oracle (oracle/) on a
+bounded sample of the same workload on rank 0 at N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="daf_stage2")
+    ap.add_argument("--plan-queries", type=int, default=480, choices=(48, 480))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def dist_setup(n):
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    return rank, world, local
+
+
+# ------------------------------------------------------------------------------------------
+class DafStage2:
+    """The deformable-aggregation calls of one stage-2 frame (forward + backward)."""
+
+    LAYERS = 6
+
+    def __init__(self, device, seed, plan_queries=480):
+        from hipad_amd import lib, synthetic as syn
+        self.lib = lib
+        lib.load()
+        g = torch.Generator().manual_seed(seed)
+        ss, st, F = syn.pyramid_tables((256, 704))
+        self.F = F
+        self.ss = torch.from_numpy(ss).to(device)
+        self.st = torch.from_numpy(st).to(device)
+        self.feat = torch.randn(1, F, 256, generator=g).to(device)
+        self.gfeat = torch.zeros_like(self.feat)
+        pm, wh = syn.projection_mats((256, 704))
+        names = ["det", "map", "plan" if plan_queries == 480 else "plan48", "ego"]
+        self.calls = []
+        self.host = {}
+        for i, n in enumerate(names):
+            kp = syn.synthetic_key_points(n, seed=seed + i)
+            loc = syn.project(kp, pm, wh)  # (1,A,P,6,2)
+            A, P = loc.shape[1:3]
+            w = torch.softmax(torch.randn(1, A, P * 6 * 4, 8, generator=g), 2).reshape(1, A, P, 6, 4, 8).contiguous()
+            gout = torch.randn(1, A, 256, generator=g)
+            loc_t = torch.from_numpy(loc).contiguous()
+            self.host[n] = (loc_t, w, gout)
+            d = dict(name=n, A=A, P=P, loc=loc_t.to(device), w=w.to(device), gout=gout.to(device))
+            d["out"] = torch.empty(1, A, 256, device=device)
+            d["gloc"] = torch.empty_like(d["loc"])
+            d["gw"] = torch.empty_like(d["w"])
+            v = (loc[..., 0] > 0) & (loc[..., 0] < 1) & (loc[..., 1] > 0) & (loc[..., 1] < 1)
+            d["kept_pairs"] = int(v.sum())
+            self.calls.append(d)
+
+    # -- algorithmic bytes -------------------------------------------
+    def alg_bytes(self, d, backward):
+        A, P = d["A"], d["P"]
+        wbytes = 4 * A * P * 6 * 4 * 8
+        lbytes = 4 * A * P * 6 * 2
+        obytes = 4 * A * 256
+        taps = 4 * d["kept_pairs"] * 4            # bilinear taps actually taken (4 levels x 4 corners)
+        fbytes = 4 * min(self.F * 256, 256 * taps)  # compulsory pyramid traffic
+        if not backward:
+            return wbytes + lbytes + obytes + fbytes
+        return (wbytes + lbytes + obytes + fbytes) + (wbytes + lbytes) + 2 * fbytes
+
+    def fwd(self, d):
+        self.lib.daf_forward(self.feat, self.ss, self.st, d["loc"], d["w"], out=d["out"])
+
+    def bwd(self, d):
+        self.lib.daf_backward(self.feat, self.ss, self.st, d["loc"], d["w"], d["gout"], self.gfeat, d["gloc"], d["gw"],
+                              overwrite_loc_w=True)
+
+    def step(self):
+        self.gfeat.zero_()  # one shared feature-gradient buffer per frame
+        for _ in range(self.LAYERS):
+            for d in self.calls:
+                self.fwd(d)
+        for _ in range(self.LAYERS):
+            for d in reversed(self.calls):
+                self.bwd(d)
+
+    def kernel_times(self, reps=20):
+        """Average launch duration (ms) of every (call, direction), HIP events on the launch stream."""
+        res = {}
+        for d in self.calls:
+            for tag, fn in (("fwd", self.fwd), ("bwd", self.bwd)):
+                fn(d)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    fn(d)
+                e1.record()
+                e1.synchronize()
+                res[(d["name"], tag)] = e0.elapsed_time(e1) / reps
+        return res
+
+    def cpu_baseline(self, seconds):
+        """CPU oracle (scalar C, 1 core) forward+backward on the first anchors of every call, sized to
+        about `seconds`; extrapolated to a frame by the kept (point,camera) pairs it covered."""
+        from oracle import daf as O
+        feat = self.feat.cpu().numpy()
+        ss, st = self.ss.cpu().numpy(), self.st.cpu().numpy()
+        total_pairs = sum(d["kept_pairs"] for d in self.calls) * self.LAYERS
+        # calibrate on a small slice
+        n0 = 8
+        d0 = self.calls[0]
+        loc, w, gout = (x.numpy() for x in self.host[d0["name"]])
+        t = time.perf_counter()
+        O.daf_forward(feat, ss, st, loc[:, :n0], w[:, :n0])
+        O.daf_backward(feat, ss, st, loc[:, :n0], w[:, :n0], gout[:, :n0])
+        dt = time.perf_counter() - t
+        lv = loc[:, :n0]
+        kept0 = int(((lv[..., 0] > 0) & (lv[..., 0] < 1) & (lv[..., 1] > 0) & (lv[..., 1] < 1)).sum())
+        per_pair = dt / max(1, kept0)
+        budget_pairs = seconds / per_pair
+        done_pairs, spent, sample = 0, 0.0, []
+        for d in self.calls:
+            loc, w, gout = (x.numpy() for x in self.host[d["name"]])
+            share = budget_pairs * d["kept_pairs"] / max(1, sum(c["kept_pairs"] for c in self.calls))
+            per_anchor = max(1.0, d["kept_pairs"] / d["A"])
+            n = int(max(1, min(d["A"], share / per_anchor)))
+            t = time.perf_counter()
+            O.daf_forward(feat, ss, st, loc[:, :n], w[:, :n])
+            O.daf_backward(feat, ss, st, loc[:, :n], w[:, :n], gout[:, :n])
+            spent += time.perf_counter() - t
+            lv = loc[:, :n]
+            done_pairs += int(((lv[..., 0] > 0) & (lv[..., 0] < 1) & (lv[..., 1] > 0) & (lv[..., 1] < 1)).sum())
+            sample.append(f"{d['name']}:{n}/{d['A']} anchors")
+        sec_per_frame = spent / max(1, done_pairs) * total_pairs
+        return dict(value=1.0 / sec_per_frame, unit="frames/s", cores=1, kind="port",
+                    sample="oracle/daf_oracle.c fwd+bwd on " + ", ".join(sample) +
+                           f" of one layer ({spent:.1f} s), scaled by kept (point,camera) pairs to 6 layers")
+
+
+def main():
+    a = parse()
+    rank, world, local = dist_setup(a.gpus)
+    dev = torch.device("cuda", local)
+    if a.workload != "daf_stage2":
+        raise SystemExit(f"unknown workload {a.workload}")
+    wl = DafStage2(dev, seed=rank, plan_queries=a.plan_queries)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        wl.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        wl.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # dominant kernel + roofline (live HIP-event timing)
+    kt = wl.kernel_times()
+    per_frame = {k: v * wl.LAYERS for k, v in kt.items()}
+    dom = max(per_frame, key=per_frame.get)
+    dcall = next(d for d in wl.calls if d["name"] == dom[0])
+    alg = wl.alg_bytes(dcall, backward=(dom[1] == "bwd"))
+    achieved = alg / (kt[dom] * 1e-3) / 1e9
+    roof = dict(bound="hbm", kernel=f"daf_{dom[1]}[{dom[0]} A={dcall['A']} P={dcall['P']}]",
+                achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+                traffic=None, alg_bytes_per_launch=alg, avg_launch_ms=round(kt[dom], 4),
+                all_kernels_ms={f"{k[0]}_{k[1]}": round(v, 4) for k, v in kt.items()})
+
+    out = dict(metric="frames/sec (6-cam 704x256, 900+100+6+48 queries) fwd+bwd at 1/2/4/8 GPUs",
+               value=round(world * a.steps / dt, 3), unit="frames/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
+               ms_per_step=round(dt / a.steps * 1e3, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
+               dtype="f32", data="synthetic",
+               config=dict(workload="daf_stage2: the 24 deformable-aggregation calls (6 layers x det 900x13, map 100x300, "
+                                    f"plan {a.plan_queries}x90, ego 1x13) fwd+bwd of one stage-2 frame, 6 cams 704x256, "
+                                    "89760-position fp32 pyramid; aggregation path only (image encoder, attention/FFN "
+                                    "and losses not included)",
+                           frames_per_gpu_per_step=1, plan_queries=a.plan_queries, parallelism=f"dp{world}"),
+               roofline=roof)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = wl.cpu_baseline(a.cpu_seconds)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,151 @@
+"""ctypes binding of libhipad.so (the C ABI declared in include/hipad.h).
+
+The product path fails loudly when the library is missing or a symbol is absent: there is
+no CPU / eager fallback anywhere behind these functions.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "csrc", "libhipad.so")
+
+c_int, c_void_p, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/hipad.h declares
+SIGNATURES = {
+    "hipad_abi_version": (c_int, []),
+    "hipad_status_string": (ctypes.c_char_p, [c_int]),
+    "hipad_daf_set_pairs_per_wave": (None, [c_int, c_int]),
+    "hipad_daf_forward_workspace": (c_size_t, [c_int] * 8),
+    "hipad_daf_forward": (c_int, [c_void_p] * 6 + [c_int] * 8 + [c_void_p, c_size_t, c_void_p]),
+    "hipad_daf_backward": (c_int, [c_void_p] * 9 + [c_int] * 8 + [c_int, c_void_p]),
+    "hipad_daf_taps": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
+}
+
+_lib = None
+
+
+class HipadError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libhipad.so and bind every declared symbol (raises if anything is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise HipadError(
+            f"{SO_PATH} not found: build it with `python hip-ad_amd/build.py` "
+            "(or __graft_entry__.build()); there is no fallback path")
+    lib = ctypes.CDLL(SO_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().hipad_status_string(status).decode()
+        raise HipadError(f"{what}: {msg} (status {status})")
+
+
+def stream_ptr(device=None):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _req(t, dtype, name):
+    if not t.is_cuda:
+        raise HipadError(f"{name} must be a device tensor (got {t.device}); the hot path has no CPU fallback")
+    if t.dtype != dtype:
+        raise HipadError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise HipadError(f"{name} must be contiguous")
+    return t
+
+
+def daf_dims(feat, spatial_shape, loc, weights):
+    if feat.dim() != 3 or spatial_shape.dim() != 3 or loc.dim() != 5 or weights.dim() != 6:
+        raise HipadError("deformable_aggregation: bad ranks "
+                         f"feat{tuple(feat.shape)} shape{tuple(spatial_shape.shape)} "
+                         f"loc{tuple(loc.shape)} weights{tuple(weights.shape)}")
+    bs, num_feat, C = feat.shape
+    cams, L = spatial_shape.shape[:2]
+    A, P = loc.shape[1:3]
+    G = weights.shape[5]
+    if tuple(loc.shape) != (bs, A, P, cams, 2) or tuple(weights.shape) != (bs, A, P, cams, L, G):
+        raise HipadError(f"deformable_aggregation: inconsistent shapes loc{tuple(loc.shape)} "
+                         f"weights{tuple(weights.shape)} for bs={bs} cams={cams} L={L}")
+    return bs, cams, num_feat, C, L, A, P, G
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    """Grow-only per-device scratch (allocated outside any timed/captured region on first use)."""
+    key = device.index
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def daf_forward(feat, spatial_shape, scale_start_index, loc, weights, out=None):
+    lib = load()
+    _req(feat, torch.float32, "feat"); _req(loc, torch.float32, "sampling_location")
+    _req(weights, torch.float32, "weights"); _req(spatial_shape, torch.int32, "spatial_shape")
+    _req(scale_start_index, torch.int32, "scale_start_index")
+    d = daf_dims(feat, spatial_shape, loc, weights)
+    bs, cams, num_feat, C, L, A, P, G = d
+    if out is None:
+        out = torch.empty(bs, A, C, dtype=torch.float32, device=feat.device)
+    nbytes = lib.hipad_daf_forward_workspace(*d)
+    ws = _workspace(nbytes, feat.device) if nbytes else None
+    with torch.cuda.device(feat.device):
+        st = lib.hipad_daf_forward(out.data_ptr(), feat.data_ptr(), spatial_shape.data_ptr(),
+                                   scale_start_index.data_ptr(), loc.data_ptr(), weights.data_ptr(), *d,
+                                   ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
+                                   stream_ptr(feat.device))
+    check(st, "hipad_daf_forward")
+    return out
+
+
+def daf_backward(feat, spatial_shape, scale_start_index, loc, weights, grad_out,
+                 grad_feat=None, grad_loc=None, grad_w=None, overwrite_loc_w=False):
+    """Accumulates into grad_feat (always) and into / over grad_loc, grad_w (see include/hipad.h)."""
+    lib = load()
+    d = daf_dims(feat, spatial_shape, loc, weights)
+    _req(grad_out, torch.float32, "grad_output")
+    for t, n in ((grad_feat, "grad_feat"), (grad_loc, "grad_loc"), (grad_w, "grad_weights")):
+        if t is not None:
+            _req(t, torch.float32, n)
+    with torch.cuda.device(feat.device):
+        st = lib.hipad_daf_backward(
+            feat.data_ptr(), spatial_shape.data_ptr(), scale_start_index.data_ptr(), loc.data_ptr(),
+            weights.data_ptr(), grad_out.data_ptr(),
+            grad_feat.data_ptr() if grad_feat is not None else None,
+            grad_loc.data_ptr() if grad_loc is not None else None,
+            grad_w.data_ptr() if grad_w is not None else None,
+            *d, 1 if overwrite_loc_w else 0, stream_ptr(feat.device))
+    check(st, "hipad_daf_backward")
+
+
+def daf_taps(spatial_shape, scale_start_index, loc, num_feat):
+    lib = load()
+    bs, A, P, cams = loc.shape[:4]
+    L = spatial_shape.shape[1]
+    valid = torch.empty(bs, A, P, cams, dtype=torch.uint8, device=loc.device)
+    taps = torch.empty(bs, A, P, cams, L, 4, dtype=torch.int32, device=loc.device)
+    with torch.cuda.device(loc.device):
+        st = lib.hipad_daf_taps(valid.data_ptr(), taps.data_ptr(), spatial_shape.data_ptr(),
+                                scale_start_index.data_ptr(), loc.data_ptr(), bs, cams, num_feat, L, A, P,
+                                stream_ptr(loc.device))
+    check(st, "hipad_daf_taps")
+    return valid, taps

@@ -109,3 +109,73 @@ def ego_motion(step, dx=1.0, dyaw_deg=1.0):
         pos += dx * np.array([-math.sin(yk), math.cos(yk)])
     T[0, 3], T[1, 3] = pos
     return T
+
+
+# ------------------------------------------------------------------------------------------
+# Query geometry for op-level benchmarks: key points of the stage-2 query sets projected
+# through the rig (what the aggregation op sees in the decoder: ~1 of 6 cameras per point).
+# ------------------------------------------------------------------------------------------
+STAGE2_QUERIES = {  # name: (anchors, points per anchor)  -- SURVEY.md section 8 table
+    "det": (900, 13),
+    "map": (100, 300),
+    "plan": (480, 90),
+    "plan48": (48, 90),
+    "ego": (1, 13),
+}
+
+
+def _data_dir():
+    import os
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "kmeans")
+
+
+def synthetic_key_points(name, bs=1, seed=0):
+    """(bs, A, P, 3) float32 numpy key points in the lidar frame for a stage-2 query set.
+
+    det/ego: box centre + 7 fixed and 6 random offsets scaled by the box size; map: the 20
+    poly-line points x 5 heights x 3 jittered copies; plan: 6 way-points x 5 heights x 3 jitter
+    for each of the (10 x) 48 trajectory modes.  Geometry only -- the learned offsets of the
+    real model are replaced by seeded noise of the same scale.
+    """
+    import os
+    rng = np.random.default_rng(seed)
+    A, P = STAGE2_QUERIES[name]
+    d = _data_dir()
+    if name in ("det", "ego"):
+        if name == "det":
+            anc = np.load(os.path.join(d, "b2d_det_900.npy")).astype(np.float32)
+        else:
+            anc = np.array([[0, 0.5, -1.06, np.log(1.9), np.log(4.9), np.log(1.6), 1, 0, 0, 0, 0]], np.float32)
+        size = np.exp(anc[:, 3:6])
+        fix = np.array([[0, 0, 0], [.45, 0, 0], [-.45, 0, 0], [0, .45, 0], [0, -.45, 0], [0, 0, .45], [0, 0, -.45]], np.float32)
+        fix = fix[: min(7, P)]
+        learn = rng.uniform(-0.5, 0.5, (A, P - len(fix), 3)).astype(np.float32)
+        offs = np.concatenate([np.broadcast_to(fix[None], (A,) + fix.shape), learn], 1) * size[:, None]
+        sin, cos = anc[:, 6], anc[:, 7]
+        x = cos[:, None] * offs[..., 0] - sin[:, None] * offs[..., 1]
+        y = sin[:, None] * offs[..., 0] + cos[:, None] * offs[..., 1]
+        kp = np.stack([x, y, offs[..., 2]], -1) + anc[:, None, :3]
+    else:
+        heights = np.array([0.0, 0.5, 1.0, 1.5, 2.0], np.float32) - 1.84023
+        if name == "map":
+            pts = np.load(os.path.join(d, "b2d_map_100.npy")).astype(np.float32)  # (100,20,2)
+        else:
+            base = np.load(os.path.join(d, "b2d_plan_spat_6x8_2m.npy")).astype(np.float32).cumsum(1)  # (48,6,2)
+            reps = A // base.shape[0]
+            pts = np.concatenate([base * (1.0 + 0.15 * k) for k in range(reps)], 0)
+        S = pts.shape[1]
+        nl = P // (S * len(heights))
+        jit = rng.normal(0, 0.5, (A, S, len(heights), nl, 2)).astype(np.float32)
+        xy = pts[:, :, None, None, :] + jit
+        z = np.broadcast_to(heights[None, None, :, None, None], xy.shape[:-1] + (1,))
+        kp = np.concatenate([xy, z], -1).reshape(A, P, 3)
+    return np.broadcast_to(kp[None], (bs,) + kp.shape).astype(np.float32).copy()
+
+
+def project(key_points, projection_mat, image_wh):
+    """numpy float32 restatement of the projection used to build benchmark inputs:
+    (bs,A,P,3) -> (bs,A,P,cams,2) normalised image coordinates."""
+    kp = np.concatenate([key_points, np.ones_like(key_points[..., :1])], -1)
+    p = np.einsum("bcij,bapj->bapci", projection_mat.astype(np.float32), kp.astype(np.float32))
+    uv = p[..., :2] / np.maximum(p[..., 2:3], np.float32(1e-5))
+    return (uv / image_wh[:, None, None]).astype(np.float32)

@@ -1,0 +1,113 @@
+/*
+ * include/hipad.h -- C ABI of libhipad.so, the MI355X (gfx950) implementation of HiP-AD's
+ * hot path.  Plain pointers and sizes only (no torch / ATen types); every pointer is a
+ * DEVICE pointer unless stated otherwise; `stream` is a hipStream_t passed as void*.
+ *
+ * Each entry point names the reference interface it replaces
+ * (reference = nullmax-vision/HiP-AD, paths relative to projects/mmdet3d_plugin/).
+ *
+ * Conventions
+ *   - return value: 0 = HIPAD_OK, otherwise a negative HIPAD_E* code (the reference's
+ *     launchers return void and never look at cudaGetLastError(); we do);
+ *   - all launches are asynchronous on `stream`; nothing here allocates, frees or
+ *     synchronises, so every call can be captured into a hipGraph;
+ *   - buffers are owned by the caller and must be contiguous in the stated layout.
+ */
+#ifndef HIPAD_H_
+#define HIPAD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIPAD_OK 0
+#define HIPAD_EINVAL (-1)      /* bad dimension / null pointer / unsupported combination */
+#define HIPAD_EWORKSPACE (-2)  /* workspace too small */
+#define HIPAD_ELAUNCH (-3)     /* hipGetLastError() reported a launch failure */
+#define HIPAD_ERANGE (-4)      /* sizes overflow the kernel's 32-bit index budget */
+
+typedef void *hipad_stream_t;
+
+/* ABI version (bumped on any signature change) and a static description string. */
+int hipad_abi_version(void);
+const char *hipad_status_string(int status);
+
+/* ------------------------------------------------------------------------------------
+ * deformable_aggregation forward.
+ * Replaces:  void deformable_aggregation(float* output, const float* mc_ms_feat,
+ *              const int* spatial_shape, const int* scale_start_index,
+ *              const float* sample_location, const float* weights, int batch_size,
+ *              int num_cams, int num_feat, int num_embeds, int num_scale, int num_anchors,
+ *              int num_pts, int num_groups)
+ *            ops/src/deformable_aggregation_cuda.cu:265-288 (kernel :129-187), called from
+ *            ops/src/deformable_aggregation.cpp:31-62.
+ * Same arguments in the same order and meaning, plus workspace and stream.
+ *   feat   [bs, num_feat, C] f32 (C = num_embeds)
+ *   spatial_shape [cams, scales, 2] i32 (h, w);  scale_start_index [cams, scales] i32
+ *   loc    [bs, A, P, cams, 2] f32 (x, y normalised to the image)
+ *   weights[bs, A, P, cams, scales, G] f32
+ *   out    [bs, A, C] f32 -- OVERWRITTEN (the reference accumulates with atomicAdd into a
+ *          tensor its shim zero-fills; the result is the same, no pre-zeroing needed here)
+ * Deterministic: no atomics, fixed summation order.
+ * workspace: hipad_daf_forward_workspace() bytes (may be 0 -> workspace may be NULL).
+ * ---------------------------------------------------------------------------------- */
+size_t hipad_daf_forward_workspace(int batch_size, int num_cams, int num_feat, int num_embeds,
+                                   int num_scale, int num_anchors, int num_pts, int num_groups);
+
+int hipad_daf_forward(float *out, const float *feat, const int32_t *spatial_shape,
+                      const int32_t *scale_start_index, const float *loc, const float *weights,
+                      int batch_size, int num_cams, int num_feat, int num_embeds, int num_scale,
+                      int num_anchors, int num_pts, int num_groups, void *workspace,
+                      size_t workspace_bytes, hipad_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * deformable_aggregation backward.
+ * Replaces:  void deformable_aggregation_grad(const float* mc_ms_feat, ..., const float*
+ *              grad_output, float* grad_mc_ms_feat, float* grad_sampling_location,
+ *              float* grad_weights, int batch_size, ... int num_groups)
+ *            ops/src/deformable_aggregation_cuda.cu:291-318 (kernel :190-262), called from
+ *            ops/src/deformable_aggregation.cpp:86-124.
+ *   grad_out  [bs, A, C];  grad_feat like feat;  grad_loc like loc;  grad_w like weights.
+ * flags:
+ *   0 (reference semantics)     all three gradients are ACCUMULATED into caller buffers
+ *                               (the reference's caller zero-fills them,
+ *                               ops/deformable_aggregation.py:55-57);
+ *   HIPAD_DAF_OVERWRITE_LOC_W   grad_loc and grad_w are fully written by the kernel (zeros
+ *                               for dropped samples) -- no memset needed; grad_feat is
+ *                               still accumulated, so one buffer can collect all call sites.
+ * grad_feat uses fp32 atomics (true scatter); grad_loc / grad_w are reduced inside the
+ * wavefront and stored once (deterministic).  Any of grad_feat / grad_loc / grad_w may be
+ * NULL to skip that gradient.
+ * ---------------------------------------------------------------------------------- */
+#define HIPAD_DAF_OVERWRITE_LOC_W 1
+
+int hipad_daf_backward(const float *feat, const int32_t *spatial_shape,
+                       const int32_t *scale_start_index, const float *loc, const float *weights,
+                       const float *grad_out, float *grad_feat, float *grad_loc, float *grad_w,
+                       int batch_size, int num_cams, int num_feat, int num_embeds, int num_scale,
+                       int num_anchors, int num_pts, int num_groups, int flags,
+                       hipad_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Index work of the operator, exposed for bit-exact checks (no reference counterpart as a
+ * function: it is the integer part of deformable_aggregation_cuda.cu:160-181 + :18-52).
+ *   valid [bs*A*P*cams] u8;  taps [bs*A*P*cams*scales*4] i32 = (h_low, w_low, mask, row)
+ *   mask bit k = corner k in bounds (k: 0 = (lo,lo), 1 = (lo,hi_w), 2 = (hi_h,lo), 3 = (hi,hi));
+ *   row = b*num_feat + scale_start_index[cam, scale]; dropped samples write zeros.
+ * ---------------------------------------------------------------------------------- */
+int hipad_daf_taps(uint8_t *valid, int32_t *taps, const int32_t *spatial_shape,
+                   const int32_t *scale_start_index, const float *loc, int batch_size,
+                   int num_cams, int num_feat, int num_scale, int num_anchors, int num_pts,
+                   hipad_stream_t stream);
+
+/* Tuning knob (host side, process-wide): target number of (point, camera) pairs one
+ * wavefront owns in the forward / backward kernels.  <=0 restores the default. */
+void hipad_daf_set_pairs_per_wave(int fwd, int bwd);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPAD_H_ */

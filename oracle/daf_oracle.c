@@ -49,8 +49,9 @@ typedef struct {
 /* cu:18-31 + cu:33-52 (bounds tests) */
 static void make_taps(int height, int width, int num_embeds, float h_im, float w_im,
                       int64_t base, taps_t *t) {
-    t->h_low = (int)floorf(h_im);
-    t->w_low = (int)floorf(w_im);
+    /* float->int of NaN is undefined in C; the GPU conversion (cvt.rzi / v_cvt_i32_f32) gives 0 */
+    t->h_low = isnan(h_im) ? 0 : (int)floorf(h_im);
+    t->w_low = isnan(w_im) ? 0 : (int)floorf(w_im);
     t->h_high = t->h_low + 1;
     t->w_high = t->w_low + 1;
     t->lh = h_im - (float)t->h_low;

@@ -1,0 +1,106 @@
+"""autograd glue for the deformable aggregation op.
+
+Mirrors the interface of the reference's ``DeformableAggregationFunction``
+(ops/deformable_aggregation.py:7-75): ``apply(mc_ms_feat, spatial_shape, scale_start_index,
+sampling_location, weights) -> output`` with gradients for feat, location and weights.
+
+Differences underneath (same results):
+  * int32 copies of the two index tables are cached on the tensors instead of being
+    re-cast by a kernel on each of the 24 calls per forward;
+  * backward lets the kernel write grad_location / grad_weights outright (no memsets);
+  * if the feature tensor came through ``shared_feature_grad`` the 24 call sites add their
+    feature gradient into ONE buffer instead of 24x (zeros + autograd add) of the pyramid.
+"""
+import torch
+from torch.autograd.function import Function, once_differentiable
+
+from hipad_amd import lib as _lib
+
+
+def _as_i32(t):
+    if t.dtype == torch.int32 and t.is_contiguous():
+        return t
+    cached = getattr(t, "_hipad_i32", None)
+    if cached is None or cached.device != t.device:
+        cached = t.contiguous().int()
+        try:
+            t._hipad_i32 = cached
+        except Exception:
+            pass
+    return cached
+
+
+def _as_f32(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class _FeatureGradSink(Function):
+    """Identity on the feature tensor; collects d(loss)/d(feat) of all consumers in one buffer."""
+
+    @staticmethod
+    def forward(ctx, feat):
+        out = feat.view_as(feat)
+        ctx.holder = holder = {"buf": None}
+        out._hipad_grad_holder = holder
+        token = torch.zeros((), dtype=feat.dtype, device=feat.device)
+        return out, token
+
+    @staticmethod
+    def backward(ctx, grad_feat, grad_token):
+        buf = ctx.holder["buf"]
+        ctx.holder["buf"] = None
+        if buf is None:
+            return grad_feat
+        return buf if grad_feat is None else buf + grad_feat
+
+
+def shared_feature_grad(feat):
+    """Route the feature gradients of every later aggregation call into one shared buffer.
+
+    Returns a tensor equal to ``feat``; pass it (inside the usual
+    ``[col_feats, spatial_shape, scale_start_index]`` triple) to the aggregation calls.
+    """
+    if not (feat.requires_grad and torch.is_grad_enabled()):
+        return feat
+    out, token = _FeatureGradSink.apply(feat)
+    out._hipad_grad_token = token
+    out._hipad_grad_holder = out._hipad_grad_holder  # keep attribute on the returned alias
+    return out
+
+
+class DeformableAggregationFunction(Function):
+    @staticmethod
+    def forward(ctx, mc_ms_feat, spatial_shape, scale_start_index, sampling_location, weights, token=None):
+        holder = getattr(mc_ms_feat, "_hipad_grad_holder", None)
+        feat = _as_f32(mc_ms_feat)
+        ss = _as_i32(spatial_shape)
+        st = _as_i32(scale_start_index)
+        loc = _as_f32(sampling_location)
+        w = _as_f32(weights)
+        output = _lib.daf_forward(feat, ss, st, loc, w)
+        ctx.save_for_backward(feat, ss, st, loc, w)
+        ctx.holder = holder if token is not None else None
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        feat, ss, st, loc, w = ctx.saved_tensors
+        need_feat, _, _, need_loc, need_w = ctx.needs_input_grad[:5]
+        grad_output = _as_f32(grad_output)
+        grad_loc = torch.empty_like(loc) if need_loc else None
+        grad_w = torch.empty_like(w) if need_w else None
+        grad_feat = ret_feat = None
+        grad_token = None
+        if ctx.holder is not None:
+            # shared sink: every call site adds into the same buffer; the sink node returns it
+            if ctx.holder["buf"] is None:
+                ctx.holder["buf"] = torch.zeros_like(feat)
+            grad_feat = ctx.holder["buf"]
+            grad_token = torch.zeros((), dtype=feat.dtype, device=feat.device)
+        elif need_feat:
+            grad_feat = ret_feat = torch.zeros_like(feat)
+        _lib.daf_backward(feat, ss, st, loc, w, grad_output, grad_feat, grad_loc, grad_w, overwrite_loc_w=True)
+        return ret_feat, None, None, grad_loc, grad_w, grad_token
