@@ -28,78 +28,9 @@
 #include <stdint.h>
 
 #include "hipad.h"
+#include "daf_common.h"
 
 namespace hipad {
-
-constexpr int kWave = 64;
-constexpr int kMaxPairsPerWave = 128;  // two (point,camera) pairs per lane
-
-// pixel coordinate exactly as deformable_aggregation_cuda.cu:180-181 computes it:
-// fl32(loc * size) then one correctly rounded subtraction of 0.5 -- never an fma.
-__device__ __forceinline__ float pix_coord(float loc, int size) {
-#pragma clang fp contract(off)
-  float prod = loc * (float)size;
-  asm volatile("" : "+v"(prod));  // opaque to the optimiser: no contraction across it
-  return prod - 0.5f;
-}
-
-__device__ __forceinline__ bool loc_kept(float lw, float lh) {
-  // cu:168-171; written so that NaN is kept, as there
-  return !(lw <= 0.f || lw >= 1.f || lh <= 0.f || lh >= 1.f);
-}
-
-struct Taps {
-  int h_low, w_low;
-  float lh, lw, hh, hw;
-  bool in_h0, in_h1, in_w0, in_w1;
-};
-
-__device__ __forceinline__ Taps make_taps(float loc_h, float loc_w, int H, int W) {
-  Taps t;
-  const float h_im = pix_coord(loc_h, H);
-  const float w_im = pix_coord(loc_w, W);
-  t.h_low = (int)floorf(h_im);
-  t.w_low = (int)floorf(w_im);
-  t.lh = h_im - (float)t.h_low;
-  t.lw = w_im - (float)t.w_low;
-  t.hh = 1.f - t.lh;
-  t.hw = 1.f - t.lw;
-  t.in_h0 = t.h_low >= 0;
-  t.in_h1 = t.h_low + 1 <= H - 1;
-  t.in_w0 = t.w_low >= 0;
-  t.in_w1 = t.w_low + 1 <= W - 1;
-  return t;
-}
-
-__device__ __forceinline__ float rl_f(float v, int lane) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-__device__ __forceinline__ int rl_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-__device__ __forceinline__ float4 sel4(bool c, float4 v) {
-  return c ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
-// Item geometry shared by forward and backward.
-struct Item {
-  int anchor;     // b*A + a
-  int b;
-  int npairs;     // (points in chunk) * cams, <= 128
-  long pair0;     // global index of the item's first (point,camera) pair
-};
-
-__device__ __forceinline__ Item make_item(int item, int nchunks, int ppc, int cams, int A, int P) {
-  Item it;
-  it.anchor = item / nchunks;
-  const int chunk = item - it.anchor * nchunks;
-  it.b = it.anchor / A;
-  const int p0 = chunk * ppc;
-  const int p1 = min(P, p0 + ppc);
-  it.npairs = (p1 - p0) * cams;
-  it.pair0 = ((long)it.anchor * P + p0) * cams;
-  return it;
-}
 
 // =====================================================================================
 // Forward, fast path: C == 256, (C/G) % 4 == 0.
@@ -268,20 +199,6 @@ __global__ __launch_bounds__(256) void daf_fwd_combine_generic_kernel(
 //   - channel 64j + l belongs to group 2j + (l >> 5): a group is one 32-lane half of one
 //     register, reduced with a 5-step butterfly.
 // =====================================================================================
-__device__ __forceinline__ float half_wave_sum(float v) {
-  // sum over the 32 lanes of this lane's half; every lane of the half gets the result
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 8);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 1);
-  return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-  v = half_wave_sum(v);
-  return v + __shfl_xor(v, 32);
-}
-
 template <int LT, bool OVERWRITE>
 __global__ __launch_bounds__(256) void daf_bwd_c256g8_kernel(
     const float *__restrict__ feat, const int *__restrict__ ss, const int *__restrict__ start,
@@ -540,8 +457,17 @@ struct Plan {
   int nchunks;  // chunks per anchor
 };
 
-static Plan make_plan(int P, int cams, int target_pairs) {
-  if (target_pairs <= 0 || target_pairs > kMaxPairsPerWave) target_pairs = kMaxPairsPerWave;
+// Work-item sizing.  One wave owns <= 128 (point,camera) pairs.  Measured on MI355X
+// (profiles/r01a_sweep_pairs_per_wave.txt): the kernels are latency-bound per wave, so more,
+// smaller items win until the per-item fixed cost shows (< ~24 pairs): aim for ~4096 waves.
+static Plan make_plan(int P, int cams, int target_pairs, long n_anchor) {
+  if (target_pairs <= 0) {
+    const long want_chunks = (4096 + n_anchor - 1) / n_anchor;
+    long ppc_auto = (P + want_chunks - 1) / want_chunks;
+    target_pairs = (int)(ppc_auto * cams);
+    if (target_pairs < 24) target_pairs = 24;
+  }
+  if (target_pairs > kMaxPairsPerWave) target_pairs = kMaxPairsPerWave;
   int ppc = target_pairs / cams;
   if (ppc < 1) ppc = 1;
   if (ppc > P) ppc = P;
@@ -590,7 +516,7 @@ void hipad_daf_set_pairs_per_wave(int fwd, int bwd) {
 
 size_t hipad_daf_forward_workspace(int bs, int cams, int num_feat, int C, int L, int A, int P, int G) {
   if (check_dims(bs, cams, num_feat, C, L, A, P, G) != HIPAD_OK) return 0;
-  const Plan pl = make_plan(P, cams, g_pairs_fwd);
+  const Plan pl = make_plan(P, cams, g_pairs_fwd, (long)bs * A);
   if (pl.nchunks == 1) return 0;
   return (size_t)bs * A * pl.nchunks * C * sizeof(float);
 }
@@ -603,7 +529,7 @@ int hipad_daf_forward(float *out, const float *feat, const int32_t *spatial_shap
   if (rc != HIPAD_OK) return rc;
   if (!out || !feat || !spatial_shape || !scale_start_index || !loc || !weights) return HIPAD_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
-  const Plan pl = make_plan(P, cams, g_pairs_fwd);
+  const Plan pl = make_plan(P, cams, g_pairs_fwd, (long)bs * A);
   const int n_anchor = bs * A;
   const int n_items = n_anchor * pl.nchunks;
   float *dst = out;
@@ -648,21 +574,42 @@ int hipad_daf_forward(float *out, const float *feat, const int32_t *spatial_shap
   return launch_status();
 }
 
+size_t hipad_daf_backward_workspace(int bs, int cams, int num_feat, int C, int L, int A, int P, int G) {
+  if (check_dims(bs, cams, num_feat, C, L, A, P, G) != HIPAD_OK) return 0;
+  const DafDims d{bs, cams, num_feat, C, L, A, P, G};
+  return daf_bwd_sorted_workspace(d);
+}
+
 int hipad_daf_backward(const float *feat, const int32_t *spatial_shape,
                        const int32_t *scale_start_index, const float *loc, const float *weights,
                        const float *grad_out, float *grad_feat, float *grad_loc, float *grad_w,
                        int bs, int cams, int num_feat, int C, int L, int A, int P, int G, int flags,
-                       hipad_stream_t stream_) {
+                       void *workspace, size_t workspace_bytes, hipad_stream_t stream_) {
   int rc = check_dims(bs, cams, num_feat, C, L, A, P, G);
   if (rc != HIPAD_OK) return rc;
   if (!feat || !spatial_shape || !scale_start_index || !loc || !weights || !grad_out) return HIPAD_EINVAL;
-  if (flags & ~HIPAD_DAF_OVERWRITE_LOC_W) return HIPAD_EINVAL;
+  if (flags & ~(HIPAD_DAF_OVERWRITE_LOC_W | HIPAD_DAF_ATOMIC_FEAT)) return HIPAD_EINVAL;
   if (!grad_feat && !grad_loc && !grad_w) return HIPAD_OK;
   hipStream_t stream = (hipStream_t)stream_;
-  const Plan pl = make_plan(P, cams, g_pairs_bwd);
+  const Plan pl = make_plan(P, cams, g_pairs_bwd, (long)bs * A);
   const int n_items = bs * A * pl.nchunks;
   const bool overwrite = (flags & HIPAD_DAF_OVERWRITE_LOC_W) != 0;
+  const DafDims d{bs, cams, num_feat, C, L, A, P, G};
   const bool fast = (C == 256) && (G == 8);
+  if (fast && !(flags & HIPAD_DAF_ATOMIC_FEAT) && daf_bwd_sorted_supported(d)) {
+    // sorted path: grad_feat by row-sorted gather, grad_loc / grad_w by the wave-per-item kernel
+    if (grad_feat) {
+      rc = daf_bwd_sorted_feat(feat, spatial_shape, scale_start_index, loc, weights, grad_out, grad_feat, d,
+                               workspace, workspace_bytes, stream);
+      if (rc != HIPAD_OK) return rc;
+    }
+    if (grad_loc || grad_w) {
+      rc = daf_bwd_lw(feat, spatial_shape, scale_start_index, loc, weights, grad_out, grad_loc, grad_w, d,
+                      pl.nchunks, pl.ppc, overwrite, stream);
+      if (rc != HIPAD_OK) return rc;
+    }
+    return launch_status();
+  }
   if (fast) {
     const int blocks = (n_items + 3) / 4;
 #define HIPAD_BWD(LT, OW)                                                                         \

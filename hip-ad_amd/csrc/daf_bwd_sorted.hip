@@ -1,0 +1,507 @@
+// hip-ad_amd/csrc/daf_bwd_sorted.hip -- backward of the deformable aggregation without the
+// atomic scatter.
+//
+// Reference semantics: deformable_aggregation_cuda.cu:190-262 + :62-126 -- per thread 4 float
+// atomicAdds into grad_feat, 1 into grad_weights (32-way contention), 2 into
+// grad_sampling_location (1024-way contention).
+//
+// Why not atomics: a stage-2 plan call scatters ~0.5 GB of fp32 adds; gfx950 retires float
+// atomics at ~1.3 TB/s chip-wide whatever the schedule (MI355X_MICROARCH.md "Global float
+// atomics"), i.e. >= 0.4 ms per call, 24 calls per frame.  The transposed problem
+//     grad_feat[row, :] += sum over taps t hitting row:  coef_t * w[t's pair, level, group(c)]
+//                                                                * grad_out[t's anchor, :]
+// is a GATHER from grad_out (<= 1 MB per call, L2 resident) once the taps are grouped by
+// destination row.  So:
+//   1. tap_pass<count>   one thread per (point,camera) pair: histogram of taps per pyramid row
+//   2. alloc             every row reserves a contiguous tap segment (block-local scan + one
+//                        atomic per 1024 rows; segments need not be in row order)
+//   3. tap_pass<place>   same walk, each tap takes a slot in its row's segment (4-byte tap id)
+//   4. feat kernel       one wave per batch of 64 row-sorted taps: lanes decode their tap in
+//                        parallel (coefficient, weights, anchor), then the wave walks the batch,
+//                        accumulating in registers while the row is unchanged and adding the
+//                        1 KiB row to grad_feat when it changes: plain read-modify-write when
+//                        the row lies wholly inside the batch (the usual case), fp32 atomics
+//                        only for rows that straddle batches.
+//   5. lw kernel         grad_weights / grad_location: one wave per (anchor, chunk of points)
+//                        as in the forward, float4 per lane, 8-lane / 64-lane butterflies,
+//                        one plain store per result (deterministic).
+// Steps 1-4 touch only index data + grad_out; step 5 re-gathers the features.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hipad.h"
+#include "daf_common.h"
+
+namespace hipad {
+
+// ------------------------------------------------------------------------------------------
+// 1 + 3: tap enumeration.  tap id = ((pair * L + s) << 2) | corner.
+//
+// A per-row global atomic per tap serialises on hot rows (a coarse 8x22 map takes a quarter of
+// all taps on ~1000 addresses: measured 0.4 ms per pass for a stage-2 plan call).  So the
+// workgroup (1024 consecutive pairs ~ a couple of anchors, spatially clustered) privatises the
+// coarse maps in LDS: phase 1 counts its taps per row in an LDS table, phase 2 issues ONE global
+// atomic per touched row (count pass: add the count; place pass: reserve `count` slots and keep
+// the returned base in the table), phase 3 (place only) re-walks the taps and draws slots from
+// the LDS cursors.  Maps too large for the table (the fine levels, few taps per row) go straight
+// to global atomics.  Which maps are "coarse" is decided on device from spatial_shape: coarsest
+// level first while every camera's map of that level still fits the table.
+// ------------------------------------------------------------------------------------------
+constexpr int kTapBlock = 1024;
+constexpr int kLdsRows = 24576;  // 96 KiB of counters
+constexpr int kMaxMaps = 64;     // cams * L handled by the LDS path
+
+template <bool PLACE>
+__global__ __launch_bounds__(kTapBlock) void daf_tap_pass_kernel(
+    int *__restrict__ counter /* cnt (count pass) or cursor (place pass) */, int *__restrict__ taps,
+    const int *__restrict__ ss, const int *__restrict__ start, const float *__restrict__ loc,
+    int npair, int cams, int num_feat, int L, int PA /* P*cams*A */) {
+  __shared__ int tab[kLdsRows];
+  __shared__ int map_base[kMaxMaps];  // LDS slot of the map's first row, or -1
+  __shared__ int used_s;
+  const int tid = threadIdx.x;
+  const int pair = blockIdx.x * kTapBlock + tid;
+  const int nmaps = cams * L;
+  const int b0 = (blockIdx.x * kTapBlock) / PA;  // sample of the block's first pair
+
+  if (tid == 0) {
+    int used = 0;
+    for (int m = 0; m < kMaxMaps; ++m) map_base[m] = -1;
+    if (nmaps <= kMaxMaps) {
+      for (int s = L - 1; s >= 0; --s) {
+        int need = 0;
+        for (int c = 0; c < cams; ++c) need += ss[2 * (c * L + s)] * ss[2 * (c * L + s) + 1];
+        if (used + need > kLdsRows) break;
+        for (int c = 0; c < cams; ++c) {
+          map_base[c * L + s] = used;
+          used += ss[2 * (c * L + s)] * ss[2 * (c * L + s) + 1];
+        }
+      }
+    }
+    used_s = used;
+  }
+  __syncthreads();
+  const int used = used_s;
+  for (int i = tid; i < used; i += kTapBlock) tab[i] = 0;
+  __syncthreads();
+
+  float2 l = make_float2(-1.f, -1.f);
+  if (pair < npair) l = reinterpret_cast<const float2 *>(loc)[pair];
+  const bool kept = pair < npair && loc_kept(l.x, l.y);
+  const int cam = pair % cams;
+  const int b = pair / PA;
+
+  // ---- phase 1: count into LDS (coarse maps of sample b0) or straight to global
+  if (kept) {
+    for (int s = 0; s < L; ++s) {
+      const int cs = cam * L + s;
+      const int H = ss[2 * cs], W = ss[2 * cs + 1];
+      const Taps t = make_taps(l.y, l.x, H, W);
+      const int lbase = (nmaps <= kMaxMaps && b == b0) ? map_base[cs] : -1;
+      const int gbase = b * num_feat + start[cs];
+      const int id0 = (pair * L + s) << 2;
+#pragma unroll
+      for (int corner = 0; corner < 4; ++corner) {
+        const bool in_h = (corner >> 1) ? t.in_h1 : t.in_h0;
+        const bool in_w = (corner & 1) ? t.in_w1 : t.in_w0;
+        if (in_h && in_w) {
+          const int rel = (t.h_low + (corner >> 1)) * W + (t.w_low + (corner & 1));
+          if (lbase >= 0) {
+            atomicAdd(&tab[lbase + rel], 1);
+          } else {
+            const int pos = atomicAdd(counter + gbase + rel, 1);
+            if (PLACE) taps[pos] = id0 | corner;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: one global atomic per touched coarse row
+  if (nmaps <= kMaxMaps) {
+    for (int m = 0; m < nmaps; ++m) {
+      const int mb = map_base[m];
+      if (mb < 0) continue;
+      const int size = ss[2 * m] * ss[2 * m + 1];
+      const int grow = b0 * num_feat + start[m];
+      for (int i = tid; i < size; i += kTapBlock) {
+        const int c = tab[mb + i];
+        if (c > 0) {
+          const int base = atomicAdd(counter + grow + i, c);
+          if (PLACE) tab[mb + i] = base;
+        }
+      }
+    }
+  }
+  if (!PLACE) return;
+  __syncthreads();
+  // ---- phase 3: draw slots from the LDS cursors
+  if (kept && b == b0 && nmaps <= kMaxMaps) {
+    for (int s = 0; s < L; ++s) {
+      const int cs = cam * L + s;
+      const int lbase = map_base[cs];
+      if (lbase < 0) continue;
+      const int H = ss[2 * cs], W = ss[2 * cs + 1];
+      const Taps t = make_taps(l.y, l.x, H, W);
+      const int id0 = (pair * L + s) << 2;
+#pragma unroll
+      for (int corner = 0; corner < 4; ++corner) {
+        const bool in_h = (corner >> 1) ? t.in_h1 : t.in_h0;
+        const bool in_w = (corner & 1) ? t.in_w1 : t.in_w0;
+        if (in_h && in_w) {
+          const int rel = (t.h_low + (corner >> 1)) * W + (t.w_low + (corner & 1));
+          const int pos = atomicAdd(&tab[lbase + rel], 1);
+          taps[pos] = id0 | corner;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// 2: segment allocation.  Rows only need CONTIGUOUS tap segments, not segments in row order,
+// so no global prefix sum: each workgroup scans its 1024 rows locally and reserves its span
+// with ONE atomicAdd on the running total (cnt[R]).  offs[r] = cursor[r] = segment start.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void daf_alloc_kernel(int *__restrict__ cnt,
+                                                         int *__restrict__ offs,
+                                                         int *__restrict__ cursor, int R) {
+  __shared__ int wsum[16];
+  __shared__ int base_s;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r = blockIdx.x * 1024 + tid;
+  const int c = r < R ? cnt[r] : 0;
+  // inclusive scan inside the wave
+  int x = c;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int y = __shfl_up(x, d);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) wsum[wv] = x;
+  __syncthreads();
+  if (wv == 0) {
+    int v = lane < 16 ? wsum[lane] : 0;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+      const int y = __shfl_up(v, d);
+      if (lane >= d) v += y;
+    }
+    if (lane < 16) wsum[lane] = v;  // inclusive over waves
+    if (lane == 15) base_s = v > 0 ? atomicAdd(cnt + R, v) : 0;  // cnt[R] = running total
+  }
+  __syncthreads();
+  if (r < R) {
+    const int o = base_s + (wv ? wsum[wv - 1] : 0) + (x - c);
+    offs[r] = o;
+    cursor[r] = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// 4: grad_feat from row-sorted taps.  C == 256, G == 8.  Persistent grid-stride over batches.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void daf_bwd_feat_kernel(
+    float *__restrict__ gfeat, const int *__restrict__ taps, const int *__restrict__ offs,
+    const int *__restrict__ ends /* cursor after placement */, const int *__restrict__ total_p,
+    const float *__restrict__ gout,
+    const float *__restrict__ loc, const float *__restrict__ wts, const int *__restrict__ ss,
+    const int *__restrict__ start, int R, int cams, int num_feat, int L, int A, int P) {
+  __shared__ float wc_s[4][kWave][8];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wv = threadIdx.x >> 6;
+  const int total = *total_p;
+  const int nbatch = (total + kWave - 1) / kWave;
+  const int nwaves = gridDim.x * 4;
+  const int g = lane >> 3;  // group of this lane's 4 channels
+  const float4 *gout4 = reinterpret_cast<const float4 *>(gout);
+  float4 *gfeat4 = reinterpret_cast<float4 *>(gfeat);
+
+  for (int batch = uni(blockIdx.x * 4 + wv); batch < nbatch; batch += nwaves) {
+    const int t0 = batch * kWave;
+    const int n = min(kWave, total - t0);
+    // ---- parallel decode: lane <-> tap
+    int row = -1, anchor = 0, excl = 0;
+    float wq[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wq[k] = 0.f;
+    if (lane < n) {
+      const int id = taps[t0 + lane];
+      const int corner = id & 3;
+      const int q = id >> 2;
+      const int pair = q / L, s = q - pair * L;
+      const int cam = pair % cams;
+      anchor = pair / (P * cams);
+      const int b = anchor / A;
+      const float2 l = reinterpret_cast<const float2 *>(loc)[pair];
+      const int cs = cam * L + s;
+      const int H = ss[2 * cs], W = ss[2 * cs + 1];
+      const Taps t = make_taps(l.y, l.x, H, W);
+      const float ch = (corner >> 1) ? t.lh : t.hh;
+      const float cw = (corner & 1) ? t.lw : t.hw;
+      const float coef = ch * cw;
+      row = b * num_feat + start[cs] + (t.h_low + (corner >> 1)) * W + (t.w_low + (corner & 1));
+      const float4 *w4 = reinterpret_cast<const float4 *>(wts) + (size_t)q * 2;
+      const float4 wa = w4[0], wb = w4[1];
+      wq[0] = coef * wa.x; wq[1] = coef * wa.y; wq[2] = coef * wa.z; wq[3] = coef * wa.w;
+      wq[4] = coef * wb.x; wq[5] = coef * wb.y; wq[6] = coef * wb.z; wq[7] = coef * wb.w;
+      excl = (offs[row] >= t0 && ends[row] <= t0 + kWave) ? 1 : 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    reinterpret_cast<float4 *>(&wc_s[wv][lane][0])[0] = make_float4(wq[0], wq[1], wq[2], wq[3]);
+    reinterpret_cast<float4 *>(&wc_s[wv][lane][0])[1] = make_float4(wq[4], wq[5], wq[6], wq[7]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- walk the batch
+    int cur = rl_i(row, 0);
+    int cur_excl = rl_i(excl, 0);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 old = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cur_excl) old = gfeat4[(size_t)cur * 64 + lane];
+    for (int t = 0; t < n; ++t) {
+      const int rt = rl_i(row, t);
+      const int at = rl_i(anchor, t);
+      const float4 g4 = gout4[(size_t)at * 64 + lane];
+      const float wc = wc_s[wv][t][g];
+      if (rt != cur) {
+        float4 *p = gfeat4 + (size_t)cur * 64 + lane;
+        if (cur_excl) {
+          *p = make_float4(old.x + acc.x, old.y + acc.y, old.z + acc.z, old.w + acc.w);
+        } else {
+          float *pf = reinterpret_cast<float *>(p);
+          atomicAdd(pf + 0, acc.x); atomicAdd(pf + 1, acc.y); atomicAdd(pf + 2, acc.z); atomicAdd(pf + 3, acc.w);
+        }
+        cur = rt;
+        cur_excl = rl_i(excl, t);
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cur_excl) old = gfeat4[(size_t)cur * 64 + lane];
+      }
+      acc.x += wc * g4.x; acc.y += wc * g4.y; acc.z += wc * g4.z; acc.w += wc * g4.w;
+    }
+    {
+      float4 *p = gfeat4 + (size_t)cur * 64 + lane;
+      if (cur_excl) {
+        *p = make_float4(old.x + acc.x, old.y + acc.y, old.z + acc.z, old.w + acc.w);
+      } else {
+        float *pf = reinterpret_cast<float *>(p);
+        atomicAdd(pf + 0, acc.x); atomicAdd(pf + 1, acc.y); atomicAdd(pf + 2, acc.z); atomicAdd(pf + 3, acc.w);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // wc_s[wv] is rewritten by the next batch
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// 5: grad_weights + grad_location.  C == 256, G == 8, one wave per item, float4 per lane.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float group8_sum(float v) {
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  return v;
+}
+
+template <int LT, bool OVERWRITE>
+__global__ __launch_bounds__(256) void daf_bwd_lw_kernel(
+    const float *__restrict__ feat, const int *__restrict__ ss, const int *__restrict__ start,
+    const float *__restrict__ loc, const float *__restrict__ wts, const float *__restrict__ gout,
+    float *__restrict__ gloc, float *__restrict__ gw, int n_items, int nchunks, int ppc, int cams,
+    int num_feat, int L_rt, int A, int P) {
+  constexpr int G = 8;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int item = uni(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  if (item >= n_items) return;
+  const int L = LT ? LT : L_rt;
+  const Item it = make_item(item, nchunks, ppc, cams, A, P);
+
+  const float2 *loc2 = reinterpret_cast<const float2 *>(loc) + it.pair0;
+  float2 l0 = make_float2(-1.f, -1.f), l1 = make_float2(-1.f, -1.f);
+  if (lane < it.npairs) l0 = loc2[lane];
+  if (lane + kWave < it.npairs) l1 = loc2[lane + kWave];
+  const int cam0 = lane % cams, cam1 = (lane + kWave) % cams;
+  const unsigned long long m0 = __ballot(lane < it.npairs && loc_kept(l0.x, l0.y));
+  const unsigned long long m1 = __ballot(lane + kWave < it.npairs && loc_kept(l1.x, l1.y));
+
+  if (OVERWRITE) {
+    if (gloc) {
+      float2 *g2 = reinterpret_cast<float2 *>(gloc) + it.pair0;
+      if (lane < it.npairs && !((m0 >> lane) & 1ull)) g2[lane] = make_float2(0.f, 0.f);
+      if (lane + kWave < it.npairs && !((m1 >> lane) & 1ull)) g2[lane + kWave] = make_float2(0.f, 0.f);
+    }
+    if (gw) {
+      float4 *g4 = reinterpret_cast<float4 *>(gw + (size_t)it.pair0 * L * G);
+      const int per_pair = L * (G / 4);
+      const int n4 = it.npairs * per_pair;
+      for (int i = lane; i < n4; i += kWave) {
+        const int q = i / per_pair;
+        const bool kept = q < kWave ? ((m0 >> q) & 1ull) : ((m1 >> (q - kWave)) & 1ull);
+        if (!kept) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  }
+
+  const float4 go = reinterpret_cast<const float4 *>(gout + (size_t)it.anchor * 256)[lane];
+  const int g = lane >> 3;
+  const float *wbase = wts + (size_t)it.pair0 * L * G + g;
+  const size_t frow0 = (size_t)it.b * num_feat;
+
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    unsigned long long m = half ? m1 : m0;
+    while (m) {
+      const int jl = __builtin_ctzll(m);
+      m &= m - 1;
+      const float loc_w = rl_f(half ? l1.x : l0.x, jl);
+      const float loc_h = rl_f(half ? l1.y : l0.y, jl);
+      const int cam = rl_i(half ? cam1 : cam0, jl);
+      const int pidx = half * kWave + jl;
+      const size_t wofs = (size_t)pidx * L * G;
+      float gl_w = 0.f, gl_h = 0.f;
+      float keep = 0.f;  // lane (g, s = lane & 7) keeps the reduced grad_w of level s
+#pragma unroll
+      for (int s = 0; s < L; ++s) {
+        const int cs = cam * L + s;
+        const int H = ss[2 * cs], W = ss[2 * cs + 1];
+        const Taps t = make_taps(loc_h, loc_w, H, W);
+        const int h0 = max(t.h_low, 0), h1 = min(t.h_low + 1, H - 1);
+        const int w0 = max(t.w_low, 0), w1 = min(t.w_low + 1, W - 1);
+        const size_t base = frow0 + (size_t)start[cs];
+        const float4 *r00 = reinterpret_cast<const float4 *>(feat + (base + (size_t)uni(h0 * W + w0)) * 256) + lane;
+        const float4 *r01 = reinterpret_cast<const float4 *>(feat + (base + (size_t)uni(h0 * W + w1)) * 256) + lane;
+        const float4 *r10 = reinterpret_cast<const float4 *>(feat + (base + (size_t)uni(h1 * W + w0)) * 256) + lane;
+        const float4 *r11 = reinterpret_cast<const float4 *>(feat + (base + (size_t)uni(h1 * W + w1)) * 256) + lane;
+        const float4 v1 = sel4(t.in_h0 && t.in_w0, *r00);
+        const float4 v2 = sel4(t.in_h0 && t.in_w1, *r01);
+        const float4 v3 = sel4(t.in_h1 && t.in_w0, *r10);
+        const float4 v4 = sel4(t.in_h1 && t.in_w1, *r11);
+        const float aw = wbase[wofs + s * G];
+        const float w1c = t.hh * t.hw, w2c = t.hh * t.lw, w3c = t.lh * t.hw, w4c = t.lh * t.lw;
+        // value, d/dh, d/dw per channel (cu:92-118), dotted with grad_out
+        float dot_val, dot_h, dot_w;
+        {
+          const float vx = w1c * v1.x + w2c * v2.x + w3c * v3.x + w4c * v4.x;
+          const float vy = w1c * v1.y + w2c * v2.y + w3c * v3.y + w4c * v4.y;
+          const float vz = w1c * v1.z + w2c * v2.z + w3c * v3.z + w4c * v4.z;
+          const float vw = w1c * v1.w + w2c * v2.w + w3c * v3.w + w4c * v4.w;
+          dot_val = go.x * vx + go.y * vy + go.z * vz + go.w * vw;
+          const float hx = t.hw * (v3.x - v1.x) + t.lw * (v4.x - v2.x);
+          const float hy = t.hw * (v3.y - v1.y) + t.lw * (v4.y - v2.y);
+          const float hz = t.hw * (v3.z - v1.z) + t.lw * (v4.z - v2.z);
+          const float hq = t.hw * (v3.w - v1.w) + t.lw * (v4.w - v2.w);
+          dot_h = go.x * hx + go.y * hy + go.z * hz + go.w * hq;
+          const float wx = t.hh * (v2.x - v1.x) + t.lh * (v4.x - v3.x);
+          const float wy = t.hh * (v2.y - v1.y) + t.lh * (v4.y - v3.y);
+          const float wz = t.hh * (v2.z - v1.z) + t.lh * (v4.z - v3.z);
+          const float wq = t.hh * (v2.w - v1.w) + t.lh * (v4.w - v3.w);
+          dot_w = go.x * wx + go.y * wy + go.z * wz + go.w * wq;
+        }
+        gl_w += (float)W * aw * dot_w;  // cu:124 with top = grad_out * weight
+        gl_h += (float)H * aw * dot_h;  // cu:125
+        if (gw) {
+          const float gs = group8_sum(dot_val);  // cu:122 summed over the group's 32 channels
+          keep = ((lane & 7) == s) ? gs : keep;
+        }
+      }
+      if (gw) {
+        if (L <= 8) {
+          if ((lane & 7) < L) {
+            float *d = gw + (size_t)it.pair0 * L * G + wofs + (lane & 7) * G + g;
+            *d = OVERWRITE ? keep : (*d + keep);
+          }
+        }
+      }
+      if (gloc) {
+        const float sw = wave_sum(gl_w), sh = wave_sum(gl_h);
+        if (lane == 0) {
+          float2 *d = reinterpret_cast<float2 *>(gloc) + it.pair0 + pidx;
+          if (OVERWRITE) {
+            *d = make_float2(sw, sh);
+          } else {
+            const float2 o = *d;
+            *d = make_float2(o.x + sw, o.y + sh);
+          }
+        }
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------- host side
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct SortedWs {
+  int *cnt, *offs, *cursor, *taps;
+  size_t bytes;
+};
+
+static SortedWs carve(const DafDims &d, void *base) {
+  const size_t R = (size_t)d.bs * d.num_feat;
+  const size_t tmax = (size_t)d.bs * d.A * d.P * d.cams * d.L * 4;
+  char *p = (char *)base;
+  SortedWs w;
+  size_t o = 0;
+  w.cnt = (int *)(p + o); o += align256((R + 1) * 4);
+  w.offs = (int *)(p + o); o += align256((R + 1) * 4);
+  w.cursor = (int *)(p + o); o += align256((R + 1) * 4);
+  w.taps = (int *)(p + o); o += align256(tmax * 4);
+  w.bytes = o;
+  return w;
+}
+
+bool daf_bwd_sorted_supported(const DafDims &d) {
+  if (d.C != 256 || d.G != 8 || d.L > 8) return false;
+  const long long tmax = (long long)d.bs * d.A * d.P * d.cams * d.L * 4;
+  return tmax < (1ll << 31) && (long long)d.bs * d.num_feat < (1ll << 30);
+}
+
+size_t daf_bwd_sorted_workspace(const DafDims &d) {
+  if (!daf_bwd_sorted_supported(d)) return 0;
+  return carve(d, nullptr).bytes;
+}
+
+int daf_bwd_sorted_feat(const float *, const int *ss, const int *start, const float *loc,
+                        const float *wts, const float *gout, float *gfeat, const DafDims &d,
+                        void *workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (!daf_bwd_sorted_supported(d)) return HIPAD_EINVAL;
+  const SortedWs w = carve(d, workspace);
+  if (!workspace || workspace_bytes < w.bytes) return HIPAD_EWORKSPACE;
+  const int R = d.bs * d.num_feat;
+  const int npair = d.bs * d.A * d.P * d.cams;
+  if (hipMemsetAsync(w.cnt, 0, (size_t)(R + 1) * 4, stream) != hipSuccess) return HIPAD_ELAUNCH;
+  const dim3 pg((npair + kTapBlock - 1) / kTapBlock), pb(kTapBlock);
+  hipLaunchKernelGGL(daf_tap_pass_kernel<false>, pg, pb, 0, stream, w.cnt, (int *)nullptr, ss, start, loc,
+                     npair, d.cams, d.num_feat, d.L, d.P * d.cams * d.A);
+  hipLaunchKernelGGL(daf_alloc_kernel, dim3((R + 1023) / 1024), dim3(1024), 0, stream, w.cnt, w.offs,
+                     w.cursor, R);
+  hipLaunchKernelGGL(daf_tap_pass_kernel<true>, pg, pb, 0, stream, w.cursor, w.taps, ss, start, loc, npair,
+                     d.cams, d.num_feat, d.L, d.P * d.cams * d.A);
+  // persistent grid: 2048 blocks x 4 waves walk the batches of 64 taps
+  const long long tmax = (long long)npair * d.L * 4;
+  long long nb = (tmax + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(daf_bwd_feat_kernel, dim3((unsigned)nb), dim3(256), 0, stream, gfeat, (const int *)w.taps,
+                     (const int *)w.offs, (const int *)w.cursor, (const int *)(w.cnt + R), gout, loc, wts, ss, start, R, d.cams, d.num_feat,
+                     d.L, d.A, d.P);
+  return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
+}
+
+int daf_bwd_lw(const float *feat, const int *ss, const int *start, const float *loc, const float *wts,
+               const float *gout, float *gloc, float *gw, const DafDims &d, int nchunks, int ppc,
+               bool overwrite, hipStream_t stream) {
+  const int n_items = d.bs * d.A * nchunks;
+  const int blocks = (n_items + 3) / 4;
+#define HIPAD_LW(LT, OW)                                                                          \
+  hipLaunchKernelGGL((daf_bwd_lw_kernel<LT, OW>), dim3(blocks), dim3(256), 0, stream, feat, ss,   \
+                     start, loc, wts, gout, gloc, gw, n_items, nchunks, ppc, d.cams, d.num_feat,  \
+                     d.L, d.A, d.P)
+  if (d.L == 4) {
+    if (overwrite) HIPAD_LW(4, true); else HIPAD_LW(4, false);
+  } else {
+    if (overwrite) HIPAD_LW(0, true); else HIPAD_LW(0, false);
+  }
+#undef HIPAD_LW
+  return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
+}
+
+}  // namespace hipad

@@ -20,7 +20,8 @@ SIGNATURES = {
     "hipad_daf_set_pairs_per_wave": (None, [c_int, c_int]),
     "hipad_daf_forward_workspace": (c_size_t, [c_int] * 8),
     "hipad_daf_forward": (c_int, [c_void_p] * 6 + [c_int] * 8 + [c_void_p, c_size_t, c_void_p]),
-    "hipad_daf_backward": (c_int, [c_void_p] * 9 + [c_int] * 8 + [c_int, c_void_p]),
+    "hipad_daf_backward_workspace": (c_size_t, [c_int] * 8),
+    "hipad_daf_backward": (c_int, [c_void_p] * 9 + [c_int] * 8 + [c_int, c_void_p, c_size_t, c_void_p]),
     "hipad_daf_taps": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
 }
 
@@ -118,7 +119,7 @@ def daf_forward(feat, spatial_shape, scale_start_index, loc, weights, out=None):
 
 
 def daf_backward(feat, spatial_shape, scale_start_index, loc, weights, grad_out,
-                 grad_feat=None, grad_loc=None, grad_w=None, overwrite_loc_w=False):
+                 grad_feat=None, grad_loc=None, grad_w=None, overwrite_loc_w=False, atomic_feat=False):
     """Accumulates into grad_feat (always) and into / over grad_loc, grad_w (see include/hipad.h)."""
     lib = load()
     d = daf_dims(feat, spatial_shape, loc, weights)
@@ -126,6 +127,9 @@ def daf_backward(feat, spatial_shape, scale_start_index, loc, weights, grad_out,
     for t, n in ((grad_feat, "grad_feat"), (grad_loc, "grad_loc"), (grad_w, "grad_weights")):
         if t is not None:
             _req(t, torch.float32, n)
+    flags = (1 if overwrite_loc_w else 0) | (2 if atomic_feat else 0)
+    nbytes = 0 if (atomic_feat or grad_feat is None) else lib.hipad_daf_backward_workspace(*d)
+    ws = _workspace(nbytes, feat.device) if nbytes else None
     with torch.cuda.device(feat.device):
         st = lib.hipad_daf_backward(
             feat.data_ptr(), spatial_shape.data_ptr(), scale_start_index.data_ptr(), loc.data_ptr(),
@@ -133,7 +137,8 @@ def daf_backward(feat, spatial_shape, scale_start_index, loc, weights, grad_out,
             grad_feat.data_ptr() if grad_feat is not None else None,
             grad_loc.data_ptr() if grad_loc is not None else None,
             grad_w.data_ptr() if grad_w is not None else None,
-            *d, 1 if overwrite_loc_w else 0, stream_ptr(feat.device))
+            *d, flags, ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
+            stream_ptr(feat.device))
     check(st, "hipad_daf_backward")
 
 

@@ -83,13 +83,25 @@ int hipad_daf_forward(float *out, const float *feat, const int32_t *spatial_shap
  * NULL to skip that gradient.
  * ---------------------------------------------------------------------------------- */
 #define HIPAD_DAF_OVERWRITE_LOC_W 1
+/*   HIPAD_DAF_ATOMIC_FEAT       use the one-pass kernel that scatters grad_feat with fp32
+ *                               atomics (needs no workspace).  Default is the sorted path:
+ *                               bilinear taps are counting-sorted by pyramid row and each row
+ *                               is accumulated in registers from L2-resident grad_out rows, so
+ *                               only rows straddling a 64-tap batch use atomics (see
+ *                               hip-ad_amd/csrc/daf_bwd_sorted.hip).  The sorted path needs
+ *                               hipad_daf_backward_workspace() bytes; that function returns 0
+ *                               for shapes it does not cover (then the atomic kernel runs). */
+#define HIPAD_DAF_ATOMIC_FEAT 2
+
+size_t hipad_daf_backward_workspace(int batch_size, int num_cams, int num_feat, int num_embeds,
+                                    int num_scale, int num_anchors, int num_pts, int num_groups);
 
 int hipad_daf_backward(const float *feat, const int32_t *spatial_shape,
                        const int32_t *scale_start_index, const float *loc, const float *weights,
                        const float *grad_out, float *grad_feat, float *grad_loc, float *grad_w,
                        int batch_size, int num_cams, int num_feat, int num_embeds, int num_scale,
-                       int num_anchors, int num_pts, int num_groups, int flags,
-                       hipad_stream_t stream);
+                       int num_anchors, int num_pts, int num_groups, int flags, void *workspace,
+                       size_t workspace_bytes, hipad_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Index work of the operator, exposed for bit-exact checks (no reference counterpart as a

@@ -37,7 +37,8 @@ def test_library_exports_every_declared_symbol():
 def test_workspace_query_is_host_only():
     from hipad_amd import lib
     L = lib.load()
-    assert L.hipad_daf_forward_workspace(1, 6, 89760, 256, 4, 900, 13, 8) == 0  # one chunk per anchor
+    assert L.hipad_daf_forward_workspace(1, 6, 89760, 256, 4, 8192, 13, 8) == 0  # one chunk per anchor
+    assert L.hipad_daf_forward_workspace(1, 6, 89760, 256, 4, 900, 13, 8) % (900 * 256 * 4) == 0
     n = L.hipad_daf_forward_workspace(1, 6, 89760, 256, 4, 100, 300, 8)
     assert n > 0 and n % (100 * 256 * 4) == 0
     assert L.hipad_daf_forward_workspace(1, 6, 89760, 250, 4, 100, 300, 8) == 0  # invalid dims

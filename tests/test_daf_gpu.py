@@ -58,7 +58,8 @@ def test_forward_vs_golden(golden, lib, case):
 
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("overwrite", [False, True])
-def test_backward_vs_golden(golden, lib, case, overwrite):
+@pytest.mark.parametrize("atomic_feat", [False, True])
+def test_backward_vs_golden(golden, lib, case, overwrite, atomic_feat):
     z, t = load_case(golden, case)
     gf = torch.zeros_like(t["feat"])
     if overwrite:  # poison: the kernel must write every element itself
@@ -66,7 +67,8 @@ def test_backward_vs_golden(golden, lib, case, overwrite):
         gw = torch.full_like(t["w"], float("nan"))
     else:
         gl, gw = torch.zeros_like(t["loc"]), torch.zeros_like(t["w"])
-    lib.daf_backward(t["feat"], t["ss"], t["st"], t["loc"], t["w"], t["gout"], gf, gl, gw, overwrite_loc_w=overwrite)
+    lib.daf_backward(t["feat"], t["ss"], t["st"], t["loc"], t["w"], t["gout"], gf, gl, gw, overwrite_loc_w=overwrite,
+                     atomic_feat=atomic_feat)
     assert rel_err(gf, z["grad_feat"]) < 2e-5
     assert rel_err(gw, z["grad_weights"]) < 2e-5
     ok = off_kink(z["loc"], z["spatial_shape"])
@@ -99,7 +101,8 @@ def make_inputs(seed, bs, A, P, shapes, cams=6, C=256, G=8, lo=-0.2, hi=1.2):
 
 
 @pytest.mark.parametrize("A,P", [(37, 13), (5, 300), (9, 90), (1, 13)])
-def test_vs_cpu_oracle_seeded(lib, A, P):
+@pytest.mark.parametrize("atomic_feat", [False, True])
+def test_vs_cpu_oracle_seeded(lib, A, P, atomic_feat):
     """det / map / plan / ego point counts on a quarter-resolution 6-cam 4-level pyramid."""
     feat, ss, st, loc, w, gout = make_inputs(10 + P, 2, A, P, [(16, 44), (8, 22), (4, 11), (2, 6)])
     ref = O.daf_forward(feat.numpy(), ss, st, loc.numpy(), w.numpy(), acc64=True)
@@ -108,7 +111,7 @@ def test_vs_cpu_oracle_seeded(lib, A, P):
     out = lib.daf_forward(*d[:5])
     assert rel_err(out, ref) < 1e-5
     gf = torch.zeros_like(d[0]); gl = torch.empty_like(d[3]); gw = torch.empty_like(d[4])
-    lib.daf_backward(*d, gf, gl, gw, overwrite_loc_w=True)
+    lib.daf_backward(*d, gf, gl, gw, overwrite_loc_w=True, atomic_feat=atomic_feat)
     assert rel_err(gf, rgf) < 1e-5
     assert rel_err(gw, rgw) < 1e-5
     assert rel_err(gl, rgl) < 1e-4  # same floor() as the oracle: no kink exclusion needed
@@ -164,6 +167,12 @@ def test_full_size_properties(lib, A, P, name):
     assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(rhs))
     lhs_f = float((gf.double() * d[0].double()).sum())  # out is linear in feat too
     assert abs(lhs_f - rhs) < 1e-4 * max(1.0, abs(rhs))
+    # the sorted path and the atomic-scatter kernel are two implementations of the same sum
+    gf2 = torch.zeros_like(d[0]); gl2 = torch.empty_like(d[3]); gw2 = torch.empty_like(d[4])
+    lib.daf_backward(*d, gf2, gl2, gw2, overwrite_loc_w=True, atomic_feat=True)
+    assert rel_err(gf2, gf.cpu().numpy()) < 1e-5
+    assert rel_err(gw2, gw.cpu().numpy()) < 1e-5
+    assert rel_err(gl2, gl.cpu().numpy()) < 1e-4
 
 
 def test_grad_loc_finite_difference(lib):

@@ -7,7 +7,7 @@ from hipad_amd import lib
 
 wl = DafStage2(torch.device("cuda", 0), 0)
 L = lib.load()
-for ppw in (128, 96, 64, 48, 32, 24, 12, 6):
+for ppw in (0, 128, 64, 32, 24, 12):
     L.hipad_daf_set_pairs_per_wave(ppw, ppw)
     kt = wl.kernel_times(reps=30)
     print(ppw, {f"{k[0]}_{k[1]}": round(v * 1e3, 1) for k, v in kt.items()}, flush=True)
