@@ -1,0 +1,276 @@
+"""Minimal stand-in for the parts of mmcv / mmdet the hot path's modules are built with.
+
+The reference instantiates every module by name through mmcv registries from Python-dict
+configs (``build_from_cfg(cfg, REGISTRY)``, projects/mmdet3d_plugin/models/sparse_onedecoder.py:203-206)
+and subclasses ``mmcv.runner.BaseModule``.  mmcv / mmdet are third-party packages that are not
+installed here (and the GPU box receives only this repo), so this file provides the handful of
+names the path needs, with the same call signatures.  When the real packages are importable
+they are used instead, so the plugin registers into the real registries under tools/train.py.
+"""
+import importlib.util
+import math
+import os
+import types
+
+import torch
+import torch.nn as nn
+
+try:  # prefer the real thing when present (drop-in under the reference's tools/)
+    from mmcv.utils import Registry, build_from_cfg  # type: ignore
+    from mmcv.cnn.bricks.registry import (ATTENTION, FEEDFORWARD_NETWORK, NORM_LAYERS,  # type: ignore
+                                          PLUGIN_LAYERS, POSITIONAL_ENCODING)
+    from mmcv.runner.base_module import BaseModule, Sequential  # type: ignore
+    from mmdet.models import DETECTORS, HEADS, LOSSES  # type: ignore
+    from mmdet.core.bbox.builder import BBOX_CODERS, BBOX_SAMPLERS  # type: ignore
+    HAVE_MMCV = True
+except Exception:  # noqa: BLE001 - any import problem means "not available"
+    HAVE_MMCV = False
+
+if not HAVE_MMCV:
+
+    class Registry:
+        """name -> class table with mmcv's ``register_module`` decorator protocol."""
+
+        def __init__(self, name):
+            self._name = name
+            self._table = {}
+
+        @property
+        def name(self):
+            return self._name
+
+        @property
+        def module_dict(self):
+            return self._table
+
+        def get(self, key):
+            return self._table.get(key)
+
+        def __contains__(self, key):
+            return key in self._table
+
+        def _add(self, cls, name=None, force=False):
+            key = name or cls.__name__
+            if not force and key in self._table and self._table[key] is not cls:
+                raise KeyError(f"{key} is already registered in {self._name}")
+            self._table[key] = cls
+
+        def register_module(self, name=None, force=False, module=None):
+            if module is not None:
+                self._add(module, name, force)
+                return module
+
+            def decorate(cls):
+                self._add(cls, name, force)
+                return cls
+
+            return decorate
+
+        def build(self, cfg, default_args=None):
+            return build_from_cfg(cfg, self, default_args)
+
+    _ALL = []
+
+    def _registry(name):
+        r = Registry(name)
+        _ALL.append(r)
+        return r
+
+    ATTENTION = _registry("attention")
+    PLUGIN_LAYERS = _registry("plugin layer")
+    POSITIONAL_ENCODING = _registry("position encoding")
+    FEEDFORWARD_NETWORK = _registry("feed-forward network")
+    NORM_LAYERS = _registry("norm layer")
+    HEADS = _registry("head")
+    DETECTORS = _registry("detector")
+    LOSSES = _registry("loss")
+    BBOX_SAMPLERS = _registry("bbox sampler")
+    BBOX_CODERS = _registry("bbox coder")
+    BACKBONES = _registry("backbone")
+    NECKS = _registry("neck")
+
+    NORM_LAYERS.register_module("LN", module=nn.LayerNorm)
+
+    def build_from_cfg(cfg, registry, default_args=None):
+        """Instantiate ``cfg['type']`` (a registered name or a class) with the remaining keys."""
+        if cfg is None:
+            return None
+        if not isinstance(cfg, dict) or "type" not in cfg:
+            raise TypeError(f"cfg must be a dict with a 'type' key, got {cfg!r}")
+        args = dict(cfg)
+        if default_args:
+            for k, v in default_args.items():
+                args.setdefault(k, v)
+        kind = args.pop("type")
+        if isinstance(kind, str):
+            cls = registry.get(kind) if registry is not None else None
+            if cls is None:  # mmcv registries have parent/child scopes; ours are flat: search all
+                for r in _ALL:
+                    cls = r.get(kind)
+                    if cls is not None:
+                        break
+            if cls is None:
+                raise KeyError(f"{kind} is not registered (looked in {getattr(registry, 'name', None)} and all others)")
+        else:
+            cls = kind
+        return cls(**args)
+
+    class BaseModule(nn.Module):
+        def __init__(self, init_cfg=None):
+            super().__init__()
+            self.init_cfg = init_cfg
+
+        def init_weights(self):
+            for m in self.children():
+                if hasattr(m, "init_weights"):
+                    m.init_weights()
+
+    class Sequential(BaseModule, nn.Sequential):
+        def __init__(self, *mods, init_cfg=None):
+            BaseModule.__init__(self, init_cfg)
+            nn.Sequential.__init__(self, *mods)
+else:
+    from mmdet.models import BACKBONES, NECKS  # type: ignore  # noqa: F401
+
+
+Linear = nn.Linear
+
+
+class Scale(nn.Module):
+    """Learnable per-channel (or scalar) multiplier (mmcv.cnn.Scale)."""
+
+    def __init__(self, scale=1.0):
+        super().__init__()
+        self.scale = nn.Parameter(torch.tensor(scale, dtype=torch.float))
+
+    def forward(self, x):
+        return x * self.scale
+
+
+def bias_init_with_prob(prior_prob):
+    return float(-math.log((1 - prior_prob) / prior_prob))
+
+
+def xavier_init(module, gain=1, bias=0, distribution="normal"):
+    if getattr(module, "weight", None) is not None:
+        (nn.init.xavier_uniform_ if distribution == "uniform" else nn.init.xavier_normal_)(module.weight, gain=gain)
+    if getattr(module, "bias", None) is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def constant_init(module, val, bias=0):
+    if getattr(module, "weight", None) is not None:
+        nn.init.constant_(module.weight, val)
+    if getattr(module, "bias", None) is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def build_activation_layer(cfg):
+    args = dict(cfg)
+    kind = args.pop("type")
+    table = {"ReLU": nn.ReLU, "GELU": nn.GELU, "Sigmoid": nn.Sigmoid, "Tanh": nn.Tanh}
+    return table[kind](**args)
+
+
+def build_norm_layer(cfg, num_features, postfix=""):
+    args = dict(cfg)
+    kind = args.pop("type")
+    if kind == "LN":
+        return f"ln{postfix}", nn.LayerNorm(num_features, **args)
+    if kind == "BN":
+        args.pop("requires_grad", None)
+        return f"bn{postfix}", nn.BatchNorm2d(num_features, **args)
+    raise KeyError(kind)
+
+
+def build_dropout(cfg, default_args=None):
+    args = dict(cfg)
+    kind = args.pop("type")
+    if kind != "Dropout":
+        raise KeyError(kind)
+    return nn.Dropout(args.pop("drop_prob", args.pop("p", 0.5)))
+
+
+def force_fp32(*dargs, **dkw):
+    """Decorator kept for signature compatibility; our modules manage precision explicitly."""
+    if len(dargs) == 1 and callable(dargs[0]) and not dkw:
+        return dargs[0]
+    return lambda fn: fn
+
+
+auto_fp16 = force_fp32
+
+
+def reduce_mean(tensor):
+    """All-reduce(mean) across ranks when torch.distributed is initialised (mmdet.core.reduce_mean)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return tensor
+    tensor = tensor.clone()
+    dist.all_reduce(tensor.div_(dist.get_world_size()), op=dist.ReduceOp.SUM)
+    return tensor
+
+
+# ------------------------------------------------------------------------------------------
+# Python-file configs (mmcv.Config.fromfile for the subset the reference's configs use)
+# ------------------------------------------------------------------------------------------
+class ConfigDict(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _wrap(obj):
+    if isinstance(obj, dict):
+        return ConfigDict({k: _wrap(v) for k, v in obj.items()})
+    if isinstance(obj, list):
+        return [_wrap(v) for v in obj]
+    if isinstance(obj, tuple):
+        return tuple(_wrap(v) for v in obj)
+    return obj
+
+
+class Config:
+    """``Config.fromfile(path, overrides=...)``: executes a Python config file and exposes its
+    public names; ``replace`` substitutes source text first (the reference configs hard-code an
+    absolute ``project_dir``, projects/configs/hipad_b2d_stage2.py:77)."""
+
+    def __init__(self, cfg_dict, filename=None):
+        object.__setattr__(self, "_cfg", _wrap(cfg_dict))
+        object.__setattr__(self, "filename", filename)
+
+    @staticmethod
+    def fromfile(path, replace=None, overrides=None):
+        with open(path) as f:
+            src = f.read()
+        for old, new in (replace or {}).items():
+            src = src.replace(old, new)
+        ns = {"__file__": os.path.abspath(path)}
+        exec(compile(src, path, "exec"), ns)
+        cfg = {k: v for k, v in ns.items() if not k.startswith("_") and not isinstance(v, types.ModuleType)
+               and not callable(v)}
+        cfg = Config(cfg, path)
+        for dotted, val in (overrides or {}).items():
+            cfg.set(dotted, val)
+        return cfg
+
+    def set(self, dotted, val):
+        node = self._cfg
+        keys = dotted.split(".")
+        for k in keys[:-1]:
+            node = node[k]
+        node[keys[-1]] = val
+
+    def __getattr__(self, k):
+        return getattr(self._cfg, k)
+
+    def __getitem__(self, k):
+        return self._cfg[k]
+
+    def get(self, k, default=None):
+        return self._cfg.get(k, default)

@@ -1,0 +1,290 @@
+// hip-ad_amd/csrc/proj_wsm.hip -- the two small fused kernels around the aggregation op:
+//
+//  (1) 3D -> 2D reference-point projection, written straight into the op's location layout.
+//      Reference: DeformableFeatureAggregation.project_points (models/blocks.py:216-225) followed
+//      by .permute(0,2,3,1,4).reshape(bs, A, P, cams, 2) (models/blocks.py:144-145).
+//      Bit-exact class: the homogeneous product is evaluated as ((m0*x + m1*y) + m2*z) + m3 with
+//      one rounding per operation and NO fma contraction -- this is the order the reference's
+//      fp32 matmul takes on the fixtures (tests/golden/project_points.npz matches bit for bit) --
+//      then clamp(z, 1e-5), two IEEE divisions.
+//
+//  (2) softmax of the sampling weights + re-layout.
+//      Reference: _get_weights (models/blocks.py:178-214): Linear(feature[a] + cam_embed[cam]) ->
+//      softmax over (cams x levels x points) per group -> optional train-time keep mask -> permute
+//      to (bs, A, P, cams, L, G) + contiguous (models/blocks.py:147-158).
+//      Here the Linear is split algebraically, W(f_a + c_k) + b = (W f_a + b) + W c_k = u[a] + v[k]
+//      (6x fewer GEMM flops, done by the host with two small GEMMs); this kernel adds u and v on the
+//      fly, does an online softmax per (anchor, group) and writes the weights ONCE, already in the
+//      op's layout (the reference writes logits, re-reads/writes them in softmax, then copies again
+//      for the permute).  Backward recomputes the softmax from (u, v, saved max/sum) and reduces
+//      d(logit) over cameras in-register -> grad_u (plain stores), over anchors -> grad_v (atomics on
+//      a 6 x n table).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hipad.h"
+
+namespace hipad {
+
+// ------------------------------------------------------------------------------------------
+// (1) projection
+// ------------------------------------------------------------------------------------------
+struct Proj {
+  float p0, p1, p2, zc;
+};
+
+__device__ __forceinline__ Proj project_one(const float *__restrict__ M, float x, float y, float z) {
+#pragma clang fp contract(off)
+  Proj r;
+  r.p0 = ((M[0] * x + M[1] * y) + M[2] * z) + M[3];
+  r.p1 = ((M[4] * x + M[5] * y) + M[6] * z) + M[7];
+  r.p2 = ((M[8] * x + M[9] * y) + M[10] * z) + M[11];
+  r.zc = fmaxf(r.p2, 1e-5f);  // torch.clamp(min=1e-5); NaN propagates through fmaxf differently,
+  if (r.p2 != r.p2) r.zc = r.p2;  // so keep NaN a NaN like torch does
+  return r;
+}
+
+__global__ __launch_bounds__(256) void project_points_fwd_kernel(
+    float *__restrict__ loc, const float *__restrict__ kp, const float *__restrict__ pm,
+    const float *__restrict__ wh, long n /* bs*A*P*cams */, int cams, long AP /* A*P */) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int cam = (int)(i % cams);
+  const long pt = i / cams;  // (b, a, p)
+  const long b = pt / AP;
+  const float *k = kp + pt * 3;
+  const float *M = pm + (b * cams + cam) * 16;
+  const Proj r = project_one(M, k[0], k[1], k[2]);
+  float u = r.p0 / r.zc, v = r.p1 / r.zc;
+  if (wh) {
+    u = u / wh[(b * cams + cam) * 2];
+    v = v / wh[(b * cams + cam) * 2 + 1];
+  }
+  reinterpret_cast<float2 *>(loc)[i] = make_float2(u, v);
+}
+
+// grad_kp[b,a,p,:] = sum_cam J^T grad_loc[b,a,p,cam,:]
+__global__ __launch_bounds__(256) void project_points_bwd_kernel(
+    float *__restrict__ gkp, const float *__restrict__ gloc, const float *__restrict__ kp,
+    const float *__restrict__ pm, const float *__restrict__ wh, long npt /* bs*A*P */, int cams,
+    long AP) {
+  const long pt = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pt >= npt) return;
+  const long b = pt / AP;
+  const float *k = kp + pt * 3;
+  const float x = k[0], y = k[1], z = k[2];
+  float gx = 0.f, gy = 0.f, gz = 0.f;
+  for (int cam = 0; cam < cams; ++cam) {
+    const float *M = pm + (b * cams + cam) * 16;
+    const Proj r = project_one(M, x, y, z);
+    const float2 g = reinterpret_cast<const float2 *>(gloc)[pt * cams + cam];
+    float gu = g.x, gv = g.y;
+    if (wh) {
+      gu = gu / wh[(b * cams + cam) * 2];
+      gv = gv / wh[(b * cams + cam) * 2 + 1];
+    }
+    const float inv = 1.f / r.zc;
+    // u = p0/zc, v = p1/zc ; d zc / d p2 = 1 where p2 > 1e-5 (clamp passes gradient only there)
+    const float gp0 = gu * inv, gp1 = gv * inv;
+    const float gp2 = (r.p2 >= 1e-5f) ? -(gu * r.p0 + gv * r.p1) * inv * inv : 0.f;
+    gx += gp0 * M[0] + gp1 * M[4] + gp2 * M[8];
+    gy += gp0 * M[1] + gp1 * M[5] + gp2 * M[9];
+    gz += gp0 * M[2] + gp1 * M[6] + gp2 * M[10];
+  }
+  gkp[pt * 3 + 0] = gx;
+  gkp[pt * 3 + 1] = gy;
+  gkp[pt * 3 + 2] = gz;
+}
+
+// ------------------------------------------------------------------------------------------
+// (2) weights softmax.  One 256-thread workgroup per (b, anchor).
+//   u [bs, A, n], v [bs, cams, n], n = L*P*G laid out ((l*P + p)*G + g)   (models/blocks.py:196-208)
+//   keep [bs, A, cams, P] float (0 or 1/(1-p_drop)) or NULL
+//   w [bs, A, P, cams, L, G];  stats [bs, A, G, 2] = (max, sum of exp)
+// The thread stride (256) is a multiple of G (G | 256 required), so a thread always meets the same
+// group g = tid % G and keeps one running (max, sum).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void online_merge(float &m, float &s, float m2, float s2) {
+  if (m2 == -INFINITY) return;  // the other side saw no element (n < 256): nothing to merge
+  if (m == -INFINITY) {
+    m = m2;
+    s = s2;
+    return;
+  }
+  const float mn = fmaxf(m, m2);
+  s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
+  m = mn;
+}
+
+__global__ __launch_bounds__(256) void weights_softmax_fwd_kernel(
+    float *__restrict__ w, float *__restrict__ stats, const float *__restrict__ u,
+    const float *__restrict__ v, const float *__restrict__ keep, int A, int cams, int L, int P, int G,
+    int ucs /* 0: u shared by the cameras, n: u holds per-camera logits [cams, n] */) {
+  __shared__ float red_m[256], red_s[256];
+  const int tid = threadIdx.x;
+  const long ba = blockIdx.x;  // b*A + a
+  const long b = ba / A;
+  const int n = L * P * G;
+  const float *ua = u + ba * (ucs ? (long)cams * n : (long)n);
+  const float *vb = v ? v + b * cams * n : nullptr;
+  // pass 1: online max / sum over this thread's (cam, j) entries, j = tid + 256*k (same g for all)
+  float m = -INFINITY, s = 0.f;
+  for (int cam = 0; cam < cams; ++cam) {
+    const float *vc = vb ? vb + (long)cam * n : nullptr;
+    const float *uc = ua + (long)cam * ucs;
+    for (int j = tid; j < n; j += 256) {
+      const float x = uc[j] + (vc ? vc[j] : 0.f);
+      if (x > m) {
+        s = s * __expf(m - x) + 1.f;
+        m = x;
+      } else {
+        s += __expf(x - m);
+      }
+    }
+  }
+  red_m[tid] = m;
+  red_s[tid] = s;
+  __syncthreads();
+  // combine the 256/G threads that share a group: tree over tid / G
+  for (int stride = 128; stride >= G; stride >>= 1) {
+    if (tid < stride) {
+      float mm = red_m[tid], sm = red_s[tid];
+      online_merge(mm, sm, red_m[tid + stride], red_s[tid + stride]);
+      red_m[tid] = mm;
+      red_s[tid] = sm;
+    }
+    __syncthreads();
+  }
+  const int g = tid % G;
+  const float gm = red_m[g], gs = red_s[g];
+  if (tid < G) {
+    stats[(ba * G + tid) * 2 + 0] = gm;
+    stats[(ba * G + tid) * 2 + 1] = gs;
+  }
+  const float inv = 1.f / gs;
+  // pass 2: write the weights in the op layout ((p*cams + cam)*L + l)*G + g
+  float *wa = w + ba * (long)cams * n;
+  for (int cam = 0; cam < cams; ++cam) {
+    const float *vc = vb ? vb + (long)cam * n : nullptr;
+    const float *uc = ua + (long)cam * ucs;
+    const float *kc = keep ? keep + (ba * cams + cam) * P : nullptr;
+    for (int j = tid; j < n; j += 256) {
+      const int lp = j / G;  // l*P + p
+      const int l = lp / P, p = lp - l * P;
+      float val = __expf(uc[j] + (vc ? vc[j] : 0.f) - gm) * inv;
+      if (kc) val *= kc[p];
+      wa[(((long)p * cams + cam) * L + l) * G + g] = val;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void weights_softmax_bwd_kernel(
+    float *__restrict__ gu, float *__restrict__ gv, const float *__restrict__ gw,
+    const float *__restrict__ stats, const float *__restrict__ u, const float *__restrict__ v,
+    const float *__restrict__ keep, int A, int cams, int L, int P, int G, int ucs) {
+  __shared__ float red[256];
+  const int tid = threadIdx.x;
+  const long ba = blockIdx.x;
+  const long b = ba / A;
+  const int n = L * P * G;
+  const float *ua = u + ba * (ucs ? (long)cams * n : (long)n);
+  const float *vb = v ? v + b * cams * n : nullptr;
+  const float *gwa = gw + ba * (long)cams * n;
+  const int g = tid % G;
+  const float gm = stats[(ba * G + g) * 2 + 0];
+  const float inv = 1.f / stats[(ba * G + g) * 2 + 1];
+  // dot[g] = sum over the softmax set of (d w) * softmax
+  float dot = 0.f;
+  for (int cam = 0; cam < cams; ++cam) {
+    const float *vc = vb ? vb + (long)cam * n : nullptr;
+    const float *uc = ua + (long)cam * ucs;
+    const float *kc = keep ? keep + (ba * cams + cam) * P : nullptr;
+    for (int j = tid; j < n; j += 256) {
+      const int lp = j / G;
+      const int l = lp / P, p = lp - l * P;
+      float gy = gwa[(((long)p * cams + cam) * L + l) * G + g];
+      if (kc) gy *= kc[p];
+      dot += gy * __expf(uc[j] + (vc ? vc[j] : 0.f) - gm) * inv;
+    }
+  }
+  red[tid] = dot;
+  __syncthreads();
+  for (int stride = 128; stride >= G; stride >>= 1) {
+    if (tid < stride) red[tid] += red[tid + stride];
+    __syncthreads();
+  }
+  const float gdot = red[g];
+  float *gua = gu + ba * (ucs ? (long)cams * n : (long)n);
+  float *gvb = gv ? gv + b * cams * n : nullptr;
+  for (int j = tid; j < n; j += 256) {
+    const int lp = j / G;
+    const int l = lp / P, p = lp - l * P;
+    float acc = 0.f;
+    for (int cam = 0; cam < cams; ++cam) {
+      const float *kc = keep ? keep + (ba * cams + cam) * P : nullptr;
+      float gy = gwa[(((long)p * cams + cam) * L + l) * G + g];
+      if (kc) gy *= kc[p];
+      const float sm = __expf(ua[(long)cam * ucs + j] + (vb ? vb[(long)cam * n + j] : 0.f) - gm) * inv;
+      const float gx = sm * (gy - gdot);
+      if (ucs) gua[(long)cam * ucs + j] = gx; else acc += gx;
+      if (gvb) atomicAdd(gvb + (long)cam * n + j, gx);
+    }
+    if (!ucs) gua[j] = acc;
+  }
+}
+
+}  // namespace hipad
+
+using namespace hipad;
+
+extern "C" {
+
+int hipad_project_points_forward(float *loc, const float *key_points, const float *projection_mat,
+                                 const float *image_wh, int bs, int A, int P, int cams,
+                                 hipad_stream_t stream) {
+  if (!loc || !key_points || !projection_mat) return HIPAD_EINVAL;
+  if (bs <= 0 || A <= 0 || P <= 0 || cams <= 0) return HIPAD_EINVAL;
+  const long n = (long)bs * A * P * cams;
+  hipLaunchKernelGGL(project_points_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, loc, key_points, projection_mat, image_wh, n, cams, (long)A * P);
+  return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
+}
+
+int hipad_project_points_backward(float *grad_key_points, const float *grad_loc, const float *key_points,
+                                  const float *projection_mat, const float *image_wh, int bs, int A, int P,
+                                  int cams, hipad_stream_t stream) {
+  if (!grad_key_points || !grad_loc || !key_points || !projection_mat) return HIPAD_EINVAL;
+  if (bs <= 0 || A <= 0 || P <= 0 || cams <= 0) return HIPAD_EINVAL;
+  const long npt = (long)bs * A * P;
+  hipLaunchKernelGGL(project_points_bwd_kernel, dim3((unsigned)((npt + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, grad_key_points, grad_loc, key_points, projection_mat, image_wh, npt,
+                     cams, (long)A * P);
+  return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
+}
+
+int hipad_weights_softmax_forward(float *weights, float *stats, const float *u, const float *v,
+                                  const float *keep, int bs, int A, int cams, int L, int P, int G,
+                                  int u_per_cam, hipad_stream_t stream) {
+  if (!weights || !stats || !u) return HIPAD_EINVAL;
+  if (bs <= 0 || A <= 0 || cams <= 0 || L <= 0 || P <= 0 || G <= 0 || 256 % G) return HIPAD_EINVAL;
+  hipLaunchKernelGGL(weights_softmax_fwd_kernel, dim3((unsigned)(bs * A)), dim3(256), 0, (hipStream_t)stream,
+                     weights, stats, u, v, keep, A, cams, L, P, G, u_per_cam ? L * P * G : 0);
+  return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
+}
+
+int hipad_weights_softmax_backward(float *grad_u, float *grad_v, const float *grad_weights,
+                                   const float *stats, const float *u, const float *v, const float *keep,
+                                   int bs, int A, int cams, int L, int P, int G, int u_per_cam,
+                                   hipad_stream_t stream) {
+  if (!grad_u || !grad_weights || !stats || !u || (v && !grad_v)) return HIPAD_EINVAL;
+  if (bs <= 0 || A <= 0 || cams <= 0 || L <= 0 || P <= 0 || G <= 0 || 256 % G) return HIPAD_EINVAL;
+  if (grad_v &&
+      hipMemsetAsync(grad_v, 0, (size_t)bs * cams * L * P * G * sizeof(float), (hipStream_t)stream) != hipSuccess)
+    return HIPAD_ELAUNCH;
+  hipLaunchKernelGGL(weights_softmax_bwd_kernel, dim3((unsigned)(bs * A)), dim3(256), 0, (hipStream_t)stream,
+                     grad_u, v ? grad_v : nullptr, grad_weights, stats, u, v, keep, A, cams, L, P, G,
+                     u_per_cam ? L * P * G : 0);
+  return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+"""autograd bindings of the HIP kernels (host-side plumbing: torch supplies memory + autograd).
+
+  project_points(key_points, projection_mat, image_wh) -> loc (bs,A,P,cams,2)
+  sampling_weights(u, v, keep, L, P, G)                -> weights (bs,A,P,cams,L,G)
+  attention / layer_norm / linear wrappers live in their own sections below as they land.
+"""
+import torch
+from torch.autograd.function import Function, once_differentiable
+
+from . import lib as _lib
+
+
+def _c32(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class _ProjectPoints(Function):
+    @staticmethod
+    def forward(ctx, key_points, projection_mat, image_wh):
+        kp, pm, wh = _c32(key_points), _c32(projection_mat), _c32(image_wh)
+        ctx.save_for_backward(kp, pm, wh)
+        return _lib.project_points_forward(kp, pm, wh)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_loc):
+        kp, pm, wh = ctx.saved_tensors
+        gkp = _lib.project_points_backward(_c32(grad_loc), kp, pm, wh) if ctx.needs_input_grad[0] else None
+        return gkp, None, None
+
+
+def project_points(key_points, projection_mat, image_wh=None):
+    """3D key points -> normalised image coordinates in the aggregation op's layout.
+
+    key_points (bs,A,P,3), projection_mat (bs,cams,4,4), image_wh (bs,cams,2) or None
+    -> (bs,A,P,cams,2).  Same arithmetic as the reference's project_points
+    (projects/mmdet3d_plugin/models/blocks.py:216-225) + its permute (blocks.py:144-145).
+    """
+    return _ProjectPoints.apply(key_points, projection_mat, image_wh)
+
+
+class _SamplingWeights(Function):
+    @staticmethod
+    def forward(ctx, u, v, keep, L, P, G):
+        u, v, keep = _c32(u), _c32(v), _c32(keep)
+        w, stats = _lib.weights_softmax_forward(u, v, keep, L, P, G)
+        ctx.save_for_backward(u, v, keep, stats)
+        ctx.dims = (L, P, G)
+        return w
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_w):
+        u, v, keep, stats = ctx.saved_tensors
+        gu, gv = _lib.weights_softmax_backward(_c32(grad_w), stats, u, v, keep, *ctx.dims)
+        return gu, gv, None, None, None, None
+
+
+def sampling_weights(u, v, keep, L, P, G):
+    """softmax over (cams, levels, points) of u[b,a,:] + v[b,cam,:] per group, written in the op
+    layout (bs,A,P,cams,L,G).  u may also be (bs,A,cams,n) with v=None.  keep: (bs,A,cams,P) or None."""
+    return _SamplingWeights.apply(u, v, keep, L, P, G)

@@ -23,6 +23,10 @@ SIGNATURES = {
     "hipad_daf_backward_workspace": (c_size_t, [c_int] * 8),
     "hipad_daf_backward": (c_int, [c_void_p] * 9 + [c_int] * 8 + [c_int, c_void_p, c_size_t, c_void_p]),
     "hipad_daf_taps": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
+    "hipad_project_points_forward": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
+    "hipad_project_points_backward": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
+    "hipad_weights_softmax_forward": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
+    "hipad_weights_softmax_backward": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p]),
 }
 
 _lib = None
@@ -154,3 +158,79 @@ def daf_taps(spatial_shape, scale_start_index, loc, num_feat):
                                 stream_ptr(loc.device))
     check(st, "hipad_daf_taps")
     return valid, taps
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def project_points_forward(key_points, projection_mat, image_wh=None):
+    """(bs,A,P,3) -> (bs,A,P,cams,2); see include/hipad.h."""
+    lib = load()
+    _req(key_points, torch.float32, "key_points"); _req(projection_mat, torch.float32, "projection_mat")
+    if image_wh is not None:
+        _req(image_wh, torch.float32, "image_wh")
+    bs, A, P = key_points.shape[:3]
+    cams = projection_mat.shape[1]
+    if key_points.shape[-1] != 3 or tuple(projection_mat.shape) != (bs, cams, 4, 4):
+        raise HipadError(f"project_points: bad shapes {tuple(key_points.shape)} {tuple(projection_mat.shape)}")
+    loc = torch.empty(bs, A, P, cams, 2, dtype=torch.float32, device=key_points.device)
+    with torch.cuda.device(key_points.device):
+        st = lib.hipad_project_points_forward(loc.data_ptr(), key_points.data_ptr(), projection_mat.data_ptr(),
+                                              _ptr(image_wh), bs, A, P, cams, stream_ptr(key_points.device))
+    check(st, "hipad_project_points_forward")
+    return loc
+
+
+def project_points_backward(grad_loc, key_points, projection_mat, image_wh=None):
+    lib = load()
+    _req(grad_loc, torch.float32, "grad_loc")
+    bs, A, P = key_points.shape[:3]
+    cams = projection_mat.shape[1]
+    gkp = torch.empty_like(key_points)
+    with torch.cuda.device(key_points.device):
+        st = lib.hipad_project_points_backward(gkp.data_ptr(), grad_loc.data_ptr(), key_points.data_ptr(),
+                                               projection_mat.data_ptr(), _ptr(image_wh), bs, A, P, cams,
+                                               stream_ptr(key_points.device))
+    check(st, "hipad_project_points_backward")
+    return gkp
+
+
+def weights_softmax_forward(u, v, keep, L, P, G):
+    """u (bs,A,n) [+ v (bs,cams,n)] or u (bs,A,cams,n) with v=None -> weights (bs,A,P,cams,L,G), stats."""
+    lib = load()
+    _req(u, torch.float32, "u")
+    if v is not None:
+        _req(v, torch.float32, "v")
+    if keep is not None:
+        _req(keep, torch.float32, "keep")
+    n = L * P * G
+    per_cam = u.dim() == 4
+    bs, A = u.shape[:2]
+    cams = u.shape[2] if per_cam else v.shape[1]
+    if u.shape[-1] != n or (v is not None and tuple(v.shape) != (bs, cams, n)) or (not per_cam and v is None):
+        raise HipadError(f"weights_softmax: bad shapes u{tuple(u.shape)} v{None if v is None else tuple(v.shape)} "
+                         f"L={L} P={P} G={G}")
+    w = torch.empty(bs, A, P, cams, L, G, dtype=torch.float32, device=u.device)
+    stats = torch.empty(bs, A, G, 2, dtype=torch.float32, device=u.device)
+    with torch.cuda.device(u.device):
+        st = lib.hipad_weights_softmax_forward(w.data_ptr(), stats.data_ptr(), u.data_ptr(), _ptr(v),
+                                               _ptr(keep), bs, A, cams, L, P, G, int(per_cam), stream_ptr(u.device))
+    check(st, "hipad_weights_softmax_forward")
+    return w, stats
+
+
+def weights_softmax_backward(grad_w, stats, u, v, keep, L, P, G):
+    lib = load()
+    _req(grad_w, torch.float32, "grad_weights")
+    per_cam = u.dim() == 4
+    bs, A = u.shape[:2]
+    cams = u.shape[2] if per_cam else v.shape[1]
+    gu = torch.empty_like(u)
+    gv = torch.empty_like(v) if v is not None else None
+    with torch.cuda.device(u.device):
+        st = lib.hipad_weights_softmax_backward(gu.data_ptr(), _ptr(gv), grad_w.data_ptr(), stats.data_ptr(),
+                                                u.data_ptr(), _ptr(v), _ptr(keep), bs, A, cams, L, P, G,
+                                                int(per_cam), stream_ptr(u.device))
+    check(st, "hipad_weights_softmax_backward")
+    return gu, gv

@@ -115,6 +115,49 @@ int hipad_daf_taps(uint8_t *valid, int32_t *taps, const int32_t *spatial_shape,
                    int num_cams, int num_feat, int num_scale, int num_anchors, int num_pts,
                    hipad_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * 3D -> 2D projection of the key points, written in the aggregation op's location layout.
+ * Replaces: DeformableFeatureAggregation.project_points (models/blocks.py:216-225) + the
+ *           permute/reshape of models/blocks.py:144-145.
+ *   key_points [bs, A, P, 3] f32;  projection_mat [bs, cams, 4, 4] f32 (row-major);
+ *   image_wh [bs, cams, 2] f32 or NULL;  loc [bs, A, P, cams, 2] f32 (overwritten).
+ * Arithmetic: ((m0*x + m1*y) + m2*z) + m3 per row without fma, clamp(z, min=1e-5), IEEE
+ * divisions -- bit-exact with the reference's fp32 result on the committed fixtures.
+ * backward: grad_key_points [bs, A, P, 3] (overwritten) from grad_loc; the projection
+ * matrices are data and receive no gradient (as in the reference's use).
+ * ---------------------------------------------------------------------------------- */
+int hipad_project_points_forward(float *loc, const float *key_points, const float *projection_mat,
+                                 const float *image_wh, int batch_size, int num_anchors, int num_pts,
+                                 int num_cams, hipad_stream_t stream);
+int hipad_project_points_backward(float *grad_key_points, const float *grad_loc,
+                                  const float *key_points, const float *projection_mat,
+                                  const float *image_wh, int batch_size, int num_anchors, int num_pts,
+                                  int num_cams, hipad_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Sampling-weight softmax fused with the re-layout.
+ * Replaces: the tail of DeformableFeatureAggregation._get_weights (models/blocks.py:196-214:
+ *           reshape -> softmax(dim=-2) -> reshape -> keep-mask) and the permute + contiguous of
+ *           models/blocks.py:147-158.
+ *   u [bs, A, n], v [bs, cams, n] f32 with n = L*P*G ordered ((l*P + p)*G + g): the logits are
+ *     u[b,a,:] + v[b,cam,:] (the Linear applied to the anchor part and to the camera part);
+ *   keep [bs, A, cams, P] f32 (0 or 1/(1-p_drop)) or NULL;
+ *   weights [bs, A, P, cams, L, G] f32 (overwritten) -- the aggregation op's layout;
+ *   stats [bs, A, G, 2] f32 (max, sum of exp) kept for the backward.  G must divide 256.
+ *   u_per_cam != 0: u is [bs, A, cams, n] (the module without camera embedding,
+ *     models/blocks.py:116-118) and v may be NULL.
+ * backward: grad_u [bs, A, n] (overwritten), grad_v [bs, cams, n] (zeroed, then accumulated).
+ * ---------------------------------------------------------------------------------- */
+int hipad_weights_softmax_forward(float *weights, float *stats, const float *u, const float *v,
+                                  const float *keep, int batch_size, int num_anchors, int num_cams,
+                                  int num_scale, int num_pts, int num_groups, int u_per_cam,
+                                  hipad_stream_t stream);
+int hipad_weights_softmax_backward(float *grad_u, float *grad_v, const float *grad_weights,
+                                   const float *stats, const float *u, const float *v,
+                                   const float *keep, int batch_size, int num_anchors, int num_cams,
+                                   int num_scale, int num_pts, int num_groups, int u_per_cam,
+                                   hipad_stream_t stream);
+
 /* Tuning knob (host side, process-wide): target number of (point, camera) pairs one
  * wavefront owns in the forward / backward kernels.  <=0 restores the default. */
 void hipad_daf_set_pairs_per_wave(int fwd, int bwd);
