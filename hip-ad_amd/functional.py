@@ -64,3 +64,31 @@ def sampling_weights(u, v, keep, L, P, G):
     """softmax over (cams, levels, points) of u[b,a,:] + v[b,cam,:] per group, written in the op
     layout (bs,A,P,cams,L,G).  u may also be (bs,A,cams,n) with v=None.  keep: (bs,A,cams,P) or None."""
     return _SamplingWeights.apply(u, v, keep, L, P, G)
+
+
+class _Attention(Function):
+    @staticmethod
+    def forward(ctx, q, k, v, heads, scale, p_drop, seed):
+        q, k, v = _c32(q), _c32(k), _c32(v)
+        need = any(ctx.needs_input_grad[:3])
+        out, lse = _lib.attention_forward(q, k, v, heads, scale, p_drop, seed, need_lse=need)
+        if need:
+            ctx.save_for_backward(q, k, v, out, lse)
+        ctx.cfg = (heads, scale, p_drop, seed)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        dq, dk, dv = _lib.attention_backward(_c32(dout), out, lse, q, k, v, *ctx.cfg)
+        return dq, dk, dv, None, None, None, None
+
+
+def attention(q, k, v, heads, scale=None, p_drop=0.0, seed=None):
+    """softmax(q k^T * scale) v per head on (B, N, heads*D) tensors (see include/hipad.h)."""
+    if scale is None:
+        scale = (q.shape[-1] // heads) ** -0.5
+    if p_drop > 0.0 and seed is None:
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    return _Attention.apply(q, k, v, heads, float(scale), float(p_drop), int(seed or 0))

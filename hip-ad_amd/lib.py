@@ -27,6 +27,10 @@ SIGNATURES = {
     "hipad_project_points_backward": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "hipad_weights_softmax_forward": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
     "hipad_weights_softmax_backward": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p]),
+    "hipad_attention_forward": (c_int, [c_void_p] * 5 + [c_int] * 5 + [ctypes.c_float, ctypes.c_float, ctypes.c_uint,
+                                                                     c_void_p]),
+    "hipad_attention_backward": (c_int, [c_void_p] * 10 + [c_int] * 5 + [ctypes.c_float, ctypes.c_float,
+                                                                       ctypes.c_uint, c_void_p]),
 }
 
 _lib = None
@@ -234,3 +238,37 @@ def weights_softmax_backward(grad_w, stats, u, v, keep, L, P, G):
                                                 int(per_cam), stream_ptr(u.device))
     check(st, "hipad_weights_softmax_backward")
     return gu, gv
+
+
+def attention_forward(q, k, v, heads, scale, p_drop=0.0, seed=0, need_lse=True):
+    """q (B,Nq,E), k/v (B,Nk,E), E = heads*D -> out (B,Nq,E), lse (B,heads,Nq) or None."""
+    lib = load()
+    _req(q, torch.float32, "q"); _req(k, torch.float32, "k"); _req(v, torch.float32, "v")
+    B, Nq, E = q.shape
+    Nk = k.shape[1]
+    if E % heads or tuple(k.shape) != (B, Nk, E) or tuple(v.shape) != (B, Nk, E):
+        raise HipadError(f"attention: bad shapes q{tuple(q.shape)} k{tuple(k.shape)} v{tuple(v.shape)} heads={heads}")
+    out = torch.empty_like(q)
+    lse = torch.empty(B, heads, Nq, dtype=torch.float32, device=q.device) if need_lse else None
+    with torch.cuda.device(q.device):
+        st = lib.hipad_attention_forward(out.data_ptr(), _ptr(lse), q.data_ptr(), k.data_ptr(), v.data_ptr(), B, heads,
+                                         Nq, Nk, E // heads, float(scale), float(p_drop), int(seed) & 0xFFFFFFFF,
+                                         stream_ptr(q.device))
+    check(st, "hipad_attention_forward")
+    return out, lse
+
+
+def attention_backward(dout, out, lse, q, k, v, heads, scale, p_drop=0.0, seed=0):
+    lib = load()
+    _req(dout, torch.float32, "dout")
+    B, Nq, E = q.shape
+    Nk = k.shape[1]
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    delta = torch.empty(B, heads, Nq, dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        st = lib.hipad_attention_backward(dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), dout.data_ptr(),
+                                          out.data_ptr(), lse.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), B,
+                                          heads, Nq, Nk, E // heads, float(scale), float(p_drop),
+                                          int(seed) & 0xFFFFFFFF, stream_ptr(q.device))
+    check(st, "hipad_attention_backward")
+    return dq, dk, dv

@@ -158,6 +158,27 @@ int hipad_weights_softmax_backward(float *grad_u, float *grad_v, const float *gr
                                    int num_scale, int num_pts, int num_groups, int u_per_cam,
                                    hipad_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Multi-head attention core: out = dropout(softmax(q k^T * softmax_scale)) v per (batch, head).
+ * Replaces: flash_attn_unpadded_kvpacked_func as called by FlashAttention.forward
+ *           (models/attention.py:76-80, 91-95; flash-attn==2.7.0.post2 is a CUDA package that is
+ *           neither vendored in the reference nor usable here), fixed-length case.
+ *   q [B, Nq, H*D], k, v [B, Nk, H*D], out [B, Nq, H*D] f32 (row-major, heads contiguous in the
+ *   last dim); D in {32, 64, 128}.  Operands are rounded to bf16 on load, fp32 accumulation on the
+ *   matrix cores, fp32 softmax (the reference runs this block in fp16/bf16, attention.py:63).
+ *   lse [B, H, Nq] f32: base-2 log-sum-exp of the scaled scores, needed by the backward (may be
+ *   NULL for inference).  p_drop / seed: dropout on the probabilities (counter-based, the
+ *   backward regenerates the same mask from the same seed).
+ * backward: dq [B,Nq,H*D], dk, dv [B,Nk,H*D] overwritten; delta_ws: B*H*Nq floats of scratch.
+ * ---------------------------------------------------------------------------------- */
+int hipad_attention_forward(float *out, float *lse, const float *q, const float *k, const float *v,
+                            int batch, int heads, int num_q, int num_k, int head_dim,
+                            float softmax_scale, float p_drop, unsigned seed, hipad_stream_t stream);
+int hipad_attention_backward(float *dq, float *dk, float *dv, float *delta_ws, const float *dout,
+                             const float *out, const float *lse, const float *q, const float *k,
+                             const float *v, int batch, int heads, int num_q, int num_k, int head_dim,
+                             float softmax_scale, float p_drop, unsigned seed, hipad_stream_t stream);
+
 /* Tuning knob (host side, process-wide): target number of (point, camera) pairs one
  * wavefront owns in the forward / backward kernels.  <=0 restores the default. */
 void hipad_daf_set_pairs_per_wave(int fwd, int bwd);
