@@ -1,0 +1,175 @@
+"""ResNet + FPN image encoder in plain torch (MIOpen convolutions), with mmdet's parameter names.
+
+The reference takes these two modules from mmdet==2.28.2 (``type="ResNet"`` / ``type="FPN"`` in
+projects/configs/hipad_b2d_stage2.py:112-134; built at models/sparse_detector.py:45-47), a
+third-party package that is not installed here.  This file restates the published architecture for
+the options those configs use -- bottleneck ResNet (depth 50/101, ``style="pytorch"``: stride on the
+3x3 conv), BatchNorm, optional activation checkpointing per stage block (``with_cp``); FPN with 1x1
+laterals without norm, nearest-neighbour top-down path, 3x3 output convs with BatchNorm -- and keeps
+mmdet's module/parameter names (``layer1.0.conv1.weight``, ``lateral_convs.0.conv.weight``,
+``fpn_convs.0.bn.weight`` ...) so ImageNet / HiP-AD checkpoints load.  Parity for it is unpinned by the
+reference's own files; tests check shapes, names and gradient flow.
+When mmdet is importable its registries already hold the real classes and these are not registered.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.utils.checkpoint as cp
+
+from hipad_amd.compat import BACKBONES, HAVE_MMCV, NECKS, BaseModule
+
+__all__ = ["ResNet", "FPN"]
+
+_DEPTH = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, with_cp=False):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.with_cp = with_cp
+
+    def _body(self, x):
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return out + (x if self.downsample is None else self.downsample(x))
+
+    def forward(self, x):
+        if self.with_cp and x.requires_grad:
+            out = cp.checkpoint(self._body, x, use_reentrant=False)
+        else:
+            out = self._body(x)
+        return self.relu(out)
+
+
+class ResNet(BaseModule):
+    def __init__(self, depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=-1, norm_eval=False,
+                 style="pytorch", with_cp=False, norm_cfg=None, pretrained=None, init_cfg=None, **kwargs):
+        super().__init__(init_cfg)
+        if depth not in _DEPTH or style != "pytorch":
+            raise NotImplementedError(f"ResNet depth={depth} style={style}")
+        self.depth, self.out_indices = depth, tuple(out_indices)
+        self.frozen_stages, self.norm_eval, self.with_cp = frozen_stages, norm_eval, with_cp
+        self.pretrained = pretrained
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        inplanes = 64
+        self.res_layers = []
+        for i, blocks in enumerate(_DEPTH[depth][:num_stages]):
+            planes, stride = 64 * 2 ** i, 1 if i == 0 else 2
+            down = None
+            if stride != 1 or inplanes != planes * 4:
+                down = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
+                                     nn.BatchNorm2d(planes * 4))
+            stage = [Bottleneck(inplanes, planes, stride, down, with_cp)]
+            inplanes = planes * 4
+            stage += [Bottleneck(inplanes, planes, with_cp=with_cp) for _ in range(1, blocks)]
+            name = f"layer{i + 1}"
+            self.add_module(name, nn.Sequential(*stage))
+            self.res_layers.append(name)
+        self._freeze()
+
+    def _freeze(self):
+        if self.frozen_stages >= 0:
+            for m in (self.conv1, self.bn1):
+                m.eval()
+                for p in m.parameters():
+                    p.requires_grad = False
+        for i in range(1, self.frozen_stages + 1):
+            m = getattr(self, f"layer{i}")
+            m.eval()
+            for p in m.parameters():
+                p.requires_grad = False
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        outs = []
+        for i, name in enumerate(self.res_layers):
+            x = getattr(self, name)(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
+
+    def train(self, mode=True):
+        super().train(mode)
+        self._freeze()
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.eval()
+        return self
+
+
+class _ConvModule(nn.Module):
+    """conv (+ BatchNorm) with mmcv.ConvModule's child names ``conv`` / ``bn``."""
+
+    def __init__(self, cin, cout, k, padding=0, with_bn=False):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, padding=padding, bias=not with_bn)
+        if with_bn:
+            self.bn = nn.BatchNorm2d(cout)
+        self.with_bn = with_bn
+
+    def forward(self, x):
+        x = self.conv(x)
+        return self.bn(x) if self.with_bn else x
+
+
+class FPN(BaseModule):
+    def __init__(self, in_channels, out_channels, num_outs, start_level=0, end_level=-1, add_extra_convs=False,
+                 relu_before_extra_convs=False, no_norm_on_lateral=False, conv_cfg=None, norm_cfg=None, act_cfg=None,
+                 upsample_cfg=dict(mode="nearest"), init_cfg=None):
+        super().__init__(init_cfg)
+        self.in_channels, self.out_channels, self.num_outs = list(in_channels), out_channels, num_outs
+        self.start_level = start_level
+        self.backbone_end_level = len(in_channels) if end_level in (-1, len(in_channels) - 1) else end_level + 1
+        used = self.backbone_end_level - start_level
+        if num_outs != used:
+            raise NotImplementedError("extra FPN levels are unused by the HiP-AD configs (num_outs == #inputs)")
+        if act_cfg is not None or conv_cfg is not None:
+            raise NotImplementedError("FPN act_cfg / conv_cfg")
+        with_bn = norm_cfg is not None
+        self.upsample_cfg = dict(upsample_cfg)
+        self.lateral_convs = nn.ModuleList(
+            _ConvModule(in_channels[i], out_channels, 1, with_bn=with_bn and not no_norm_on_lateral)
+            for i in range(start_level, self.backbone_end_level))
+        self.fpn_convs = nn.ModuleList(_ConvModule(out_channels, out_channels, 3, padding=1, with_bn=with_bn)
+                                       for _ in range(used))
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def forward(self, inputs):
+        lat = [conv(inputs[i + self.start_level]) for i, conv in enumerate(self.lateral_convs)]
+        for i in range(len(lat) - 1, 0, -1):
+            lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], size=lat[i - 1].shape[2:], **self.upsample_cfg)
+        return tuple(conv(x) for conv, x in zip(self.fpn_convs, lat))
+
+
+if not HAVE_MMCV:
+    BACKBONES.register_module("ResNet", module=ResNet)
+    NECKS.register_module("FPN", module=FPN)

@@ -1,0 +1,96 @@
+"""Planning refinement heads (registered names / keywords / parameter names of the reference's
+models/plan/blocks.py:16-157)."""
+import torch
+import torch.nn as nn
+
+from hipad_amd.compat import PLUGIN_LAYERS, BaseModule, Linear, Scale, bias_init_with_prob
+
+from ..blocks import linear_relu_ln
+
+__all__ = ["SparsePlanRefinementModule", "SparsePlanAlignRefinementModule"]
+
+
+def _cls_head(embed_dims):
+    return nn.Sequential(*linear_relu_ln(embed_dims, 1, 2), Linear(embed_dims, 1))
+
+
+def _reg_head(embed_dims, out_dim):
+    return nn.Sequential(*linear_relu_ln(embed_dims, 2, 2), Linear(embed_dims, out_dim), Scale([1.0] * out_dim))
+
+
+@PLUGIN_LAYERS.register_module()
+class SparsePlanRefinementModule(BaseModule):
+    def __init__(self, embed_dims=256, ego_fut_ts=6, ego_fut_cmd=3, ego_fut_mode=3, add_anchor=False):
+        super().__init__()
+        self.embed_dims, self.ego_fut_ts, self.ego_fut_cmd, self.ego_fut_mode = embed_dims, ego_fut_ts, ego_fut_cmd, ego_fut_mode
+        self.add_anchor = add_anchor
+        self.plan_cls_branch = _cls_head(embed_dims)
+        self.plan_reg_branch = _reg_head(embed_dims, ego_fut_ts * 2)
+
+    def init_weight(self):
+        nn.init.constant_(self.plan_cls_branch[-1].bias, bias_init_with_prob(0.01))
+
+    def forward(self, instance_feature, anchor, anchor_embed, use_plan_anchor_embed=True):
+        src = instance_feature + anchor_embed if use_plan_anchor_embed else instance_feature
+        return self.plan_reg_branch(src) + anchor, self.plan_cls_branch(instance_feature)
+
+
+@PLUGIN_LAYERS.register_module()
+class SparsePlanAlignRefinementModule(BaseModule):
+    """Way-point regression for several anchor groups that share their mode scores.
+
+    The query tensor holds ``len(anchor_types)`` equal chunks (one per anchor group).  All
+    "temp"/"spat" groups are summed into one aligned query that feeds their regression branches and
+    one shared score branch; each "speed" group adds, on top of that, the sum of the speed groups of
+    its speed interval over the frequencies, and is scored by a second branch (reference
+    models/plan/blocks.py:53-157).
+    """
+
+    def __init__(self, embed_dims=256, ego_fut_ts=6, ego_fut_cmd=3, ego_fut_mode=3, anchor_types=None):
+        super().__init__()
+        self.embed_dims, self.ego_fut_ts, self.ego_fut_cmd, self.ego_fut_mode = embed_dims, ego_fut_ts, ego_fut_cmd, ego_fut_mode
+        self.anchor_types = anchor_types
+        self.anchor_group = len(anchor_types)
+        self.plan_cls_branch = _cls_head(embed_dims)
+        by_freq = {}
+        for t in anchor_types:
+            if t[0] == "speed":
+                by_freq.setdefault(t[1], []).append(t[2])
+        if by_freq:
+            areas = list(by_freq.values())
+            self.speed_areas = areas[0]
+            if any(a != self.speed_areas for a in areas[1:]):
+                raise AssertionError("every speed frequency must list the same intervals")
+            self.plan_cls_branch_speed = _cls_head(embed_dims)
+        for t in anchor_types:
+            name = f"plan_reg_branch_{t[0]}_{t[1]}"
+            setattr(self, name, _reg_head(embed_dims, ego_fut_ts * 2))  # same-named groups share (last one wins)
+
+    def init_weight(self):
+        prior = bias_init_with_prob(0.01)
+        nn.init.constant_(self.plan_cls_branch[-1].bias, prior)
+        if hasattr(self, "plan_cls_branch_speed"):
+            nn.init.constant_(self.plan_cls_branch_speed[-1].bias, prior)
+
+    def forward(self, instance_feature, anchor, anchor_embed, use_plan_anchor_embed=True):
+        if use_plan_anchor_embed:
+            instance_feature = instance_feature + anchor_embed
+        chunks = instance_feature.chunk(self.anchor_group, dim=1)
+        aligned = sum(c for c, t in zip(chunks, self.anchor_types) if t[0] in ("temp", "spat"))
+        speed_query = {}
+        if hasattr(self, "speed_areas"):
+            for area in self.speed_areas:
+                same_area = [c for c, t in zip(chunks, self.anchor_types) if t[0] == "speed" and t[2] == area]
+                speed_query[area] = aligned + sum(same_area)
+        regs, scores = [], []
+        for t in self.anchor_types:
+            branch = getattr(self, f"plan_reg_branch_{t[0]}_{t[1]}")
+            if t[0] in ("temp", "spat"):
+                src, head = aligned, self.plan_cls_branch
+            elif t[0] == "speed":
+                src, head = speed_query[t[2]], self.plan_cls_branch_speed
+            else:
+                raise NotImplementedError(t[0])
+            regs.append(branch(src))
+            scores.append(head(src))
+        return torch.cat(regs, dim=1) + anchor, torch.cat(scores, dim=1)

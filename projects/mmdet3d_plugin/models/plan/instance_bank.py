@@ -1,0 +1,147 @@
+"""Planning query store: trajectory-mode anchors of every anchor group, a query feature pooled from
+the front camera's coarsest pyramid level, and a per-command-group temporal cache.
+
+Registered name, constructor keywords, parameter names (``anchor``, ``plan_feature_encoder.*``) and the
+get / update / cache protocol follow the reference's ``PlanningInstanceBank``
+(models/plan/instance_bank.py:24-262).
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from hipad_amd.compat import PLUGIN_LAYERS, Linear
+from projects.mmdet3d_plugin.ops import feature_maps_format
+
+from ..blocks import linear_relu_ln
+from ..instance_bank import select_topk
+
+__all__ = ["PlanningInstanceBank", "front_view_encoder"]
+
+
+def front_view_encoder(embed_dims, feature_map_scale):
+    """conv3x3 - BN - conv3x3/2 - BN - ReLU - average pool to 1x1 (kernel = half the level size)."""
+    kernel = tuple(int(x / 2) for x in feature_map_scale)
+    return nn.Sequential(
+        nn.Conv2d(embed_dims, embed_dims, 3, stride=1, padding=1, bias=False), nn.BatchNorm2d(embed_dims),
+        nn.Conv2d(embed_dims, embed_dims, 3, stride=2, padding=1, bias=False), nn.BatchNorm2d(embed_dims),
+        nn.ReLU(), nn.AvgPool2d(kernel))
+
+
+@PLUGIN_LAYERS.register_module()
+class PlanningInstanceBank(nn.Module):
+    def __init__(self, embed_dims, anchor_paths, anchor_types=None, anchor_scales=None, num_temp_mode=0,
+                 num_temp_instances=0, confidence_decay=0.6, feature_map_scale=None, max_time_interval=2,
+                 feat_grad=True, anchor_grad=True, ego_fut_ts=6, ego_fut_cmd=3, ego_fut_mode=6,
+                 with_instance_feat=False, with_all_front_views=False, with_custom_status_embed=False):
+        super().__init__()
+        self.embed_dims, self.ego_fut_ts, self.ego_fut_cmd, self.ego_fut_mode = embed_dims, ego_fut_ts, ego_fut_cmd, ego_fut_mode
+        self.num_temp_mode, self.num_temp_instances = num_temp_mode, num_temp_instances
+        self.confidence_decay, self.max_time_interval = confidence_decay, max_time_interval
+        self.with_instance_feat, self.with_all_front_views = with_instance_feat, with_all_front_views
+        self.with_custom_status_embed = with_custom_status_embed
+        self.anchor_paths, self.anchor_types = anchor_paths, anchor_types
+        self.anchor_group = self.ego_mode_group = len(anchor_types)
+        scales = [1.0] * len(anchor_types) if anchor_scales is None else anchor_scales
+        if anchor_paths is None or len(scales) != len(anchor_types):
+            raise AssertionError("anchor_paths / anchor_scales do not match anchor_types")
+        if isinstance(anchor_paths, str):
+            path_of = {t: anchor_paths for t in anchor_types}
+        elif isinstance(anchor_paths, (list, tuple)):
+            path_of = dict(zip(anchor_types, anchor_paths))
+        elif isinstance(anchor_paths, dict):
+            path_of = anchor_paths
+        else:
+            raise NotImplementedError(type(anchor_paths))
+        tables = []
+        for t, scale in zip(anchor_types, scales):
+            arr = np.load(path_of[t])
+            arr = arr.reshape(-1, arr.shape[-2] * arr.shape[-1])  # (modes[, cmds], ts, 2) -> (N, ts*2)
+            tables.append(arr * scale)
+        self.anchor = nn.Parameter(torch.tensor(np.concatenate(tables, axis=0), dtype=torch.float32),
+                                   requires_grad=anchor_grad)
+        self.num_anchor = len(self.anchor)
+        if with_instance_feat:
+            self.instance_feature = nn.Parameter(torch.zeros(self.num_anchor, embed_dims), requires_grad=feat_grad)
+        else:
+            self.plan_feature_encoder = front_view_encoder(embed_dims, feature_map_scale)
+        if with_custom_status_embed:
+            self.custom_status_encoder = nn.Sequential(*linear_relu_ln(embed_dims, 2, 1, input_dims=6),
+                                                       Linear(embed_dims, embed_dims))
+        self.reset()
+
+    def reset(self):
+        self.cached_feature = self.cached_anchor = None
+        self.confidence = self.metas = self.mask = None
+
+    def prepare_planning(self, batch_size, feature_maps, metas=None):
+        if self.with_instance_feat:
+            feature = self.instance_feature[None].expand(batch_size, -1, -1).contiguous()
+        else:
+            coarsest = feature_maps_format(feature_maps, inverse=True)[0][-1]  # (bs, cams, C, h, w)
+            if self.with_all_front_views:
+                bs, nc, C, h, w = coarsest[:, :3].shape
+                pooled = self.plan_feature_encoder(coarsest[:, :3].reshape(-1, C, h, w)).reshape(bs, nc, C).sum(1)
+            else:
+                pooled = self.plan_feature_encoder(coarsest[:, 0]).flatten(1)  # centre front camera
+            if self.with_custom_status_embed:
+                pooled = pooled + self.custom_status_encoder(metas["custom_status"])
+            feature = pooled[:, None].expand(-1, self.num_anchor, -1).contiguous()
+        anchor = self.anchor[None].expand(batch_size, -1, -1).contiguous()
+        return feature, anchor
+
+    def get(self, batch_size, metas, feature_maps, dn_metas=None):
+        feature, anchor = self.prepare_planning(batch_size, feature_maps, metas)
+        if self.cached_anchor is None:
+            return feature, anchor, None, None
+        dt = (metas["timestamp"] - self.metas["timestamp"]).to(feature.dtype)
+        self.mask = dt.abs() <= self.max_time_interval
+        bs = anchor.shape[0]
+        return (feature, anchor, self.cached_feature.reshape(bs, -1, self.embed_dims),
+                self.cached_anchor.reshape(bs, -1, self.ego_fut_ts * 2))
+
+    def _per_command(self, bs, *tensors):
+        groups = self.ego_fut_cmd * self.anchor_group
+        return [t.reshape(bs * groups, -1, t.shape[-1]) for t in tensors]
+
+    def update(self, instance_feature, anchor, confidence):
+        if self.cached_feature is None:
+            return instance_feature, anchor
+        extra = instance_feature.shape[1] - self.num_anchor
+        tail = None
+        if extra > 0:
+            tail = (instance_feature[:, -extra:], anchor[:, -extra:])
+            instance_feature, anchor, confidence = (t[:, : self.num_anchor] for t in (instance_feature, anchor, confidence))
+        bs = anchor.shape[0]
+        groups = self.ego_fut_cmd * self.anchor_group
+        f, a, c = self._per_command(bs, instance_feature, anchor, confidence.reshape(bs, -1, 1))
+        fresh = self.ego_fut_mode - self.num_temp_mode
+        _, (top_f, top_a) = select_topk(c.max(dim=-1).values, fresh, f, a)
+        top_f = top_f.reshape(bs, groups, fresh, self.embed_dims)
+        top_a = top_a.reshape(bs, groups, fresh, self.ego_fut_ts * 2)
+        merged_f = torch.cat([self.cached_feature, top_f], dim=2).reshape(bs, -1, self.embed_dims)
+        merged_a = torch.cat([self.cached_anchor, top_a], dim=2).reshape(bs, -1, self.ego_fut_ts * 2)
+        usable = self.mask[:, None, None]
+        instance_feature = torch.where(usable, merged_f, instance_feature)
+        anchor = torch.where(usable, merged_a, anchor)
+        self.confidence = torch.where(usable, self.confidence, self.confidence.new_tensor(0))
+        if tail is not None:
+            instance_feature = torch.cat([instance_feature, tail[0]], dim=1)
+            anchor = torch.cat([anchor, tail[1]], dim=1)
+        return instance_feature, anchor
+
+    def cache(self, instance_feature, anchor, confidence, metas=None, feature_maps=None):
+        if self.num_temp_mode <= 0:
+            return
+        bs = anchor.shape[0]
+        groups = self.ego_fut_cmd * self.anchor_group
+        f, a, c = self._per_command(bs, instance_feature.detach(), anchor.detach(), confidence.detach().reshape(bs, -1, 1))
+        self.metas = metas
+        score = c.squeeze(-1).sigmoid()
+        if self.confidence is not None:
+            n = self.num_temp_mode
+            old = self.confidence.reshape(bs * groups, -1) * self.confidence_decay
+            score = torch.cat([torch.maximum(old, score[:, :n]), score[:, n:]], dim=1)
+        conf, (kept_f, kept_a) = select_topk(score, self.num_temp_mode, f, a)
+        self.confidence = conf.view(bs, groups, self.num_temp_mode)
+        self.cached_feature = kept_f.view(bs, groups, self.num_temp_mode, self.embed_dims)
+        self.cached_anchor = kept_a.view(bs, groups, self.num_temp_mode, self.ego_fut_ts * 2)

@@ -1,0 +1,93 @@
+"""Detector shell: multi-view images -> ResNet/FPN pyramid -> flat column layout -> unified decoder.
+
+Registered name ``SparseDetector``; constructor keywords, child names (``img_backbone``, ``img_neck``,
+``head``, ``depth_branch``, ``grid_mask``) and the ``extract_feat`` / ``forward_train`` /
+``simple_test`` entry points follow the reference (models/sparse_detector.py:25-174).
+
+MI355X specifics: the encoder runs channels-last under bf16 autocast (the reference's ``fp16 =
+dict(loss_scale=32.0)`` / ``@auto_fp16`` becomes bf16: same exponent range as fp32, no loss scaling),
+the pyramid is cast back to fp32 for the aggregation kernels exactly as the reference does
+(``out_fp32=True``), and all later aggregation calls share one feature-gradient buffer
+(``shared_feature_grad``).
+"""
+import torch
+
+from hipad_amd.compat import BACKBONES, DETECTORS, HEADS, NECKS, PLUGIN_LAYERS, BaseModule, build_from_cfg
+
+from ..ops import feature_maps_format, shared_feature_grad
+from .grid_mask import GridMask
+
+__all__ = ["SparseDetector"]
+
+
+@DETECTORS.register_module()
+class SparseDetector(BaseModule):
+    def __init__(self, img_backbone, head, img_neck=None, init_cfg=None, train_cfg=None, test_cfg=None,
+                 pretrained=None, use_grid_mask=True, use_deformable_func=False, depth_branch=None,
+                 scenes_tokenizer=None, encoder_dtype=torch.bfloat16):
+        super().__init__(init_cfg)
+        if scenes_tokenizer is not None:
+            raise NotImplementedError("scene tokens are not used by the HiP-AD configs")
+        if not use_deformable_func:
+            raise ValueError("this build runs the aggregation op only (use_deformable_func=True)")
+        if pretrained is not None:
+            img_backbone = dict(img_backbone, pretrained=pretrained)
+        self.img_backbone = build_from_cfg(img_backbone, BACKBONES)
+        self.img_neck = build_from_cfg(img_neck, NECKS) if img_neck is not None else None
+        self.head = build_from_cfg(head, HEADS)
+        self.use_grid_mask, self.use_deformable_func = use_grid_mask, use_deformable_func
+        self.depth_branch = build_from_cfg(depth_branch, PLUGIN_LAYERS) if depth_branch is not None else None
+        self.scenes_tokenizer = None
+        if use_grid_mask:
+            self.grid_mask = GridMask(True, True, rotate=1, offset=False, ratio=0.5, mode=1, prob=0.7)
+        self.encoder_dtype = encoder_dtype
+
+    def init_weights(self):
+        for m in (self.img_backbone, self.img_neck, self.head):
+            if m is not None and hasattr(m, "init_weights"):
+                m.init_weights()
+
+    def extract_feat(self, img, return_depth=False, metas=None):
+        bs = img.shape[0]
+        if img.dim() == 5:
+            num_cams = img.shape[1]
+            img = img.flatten(end_dim=1)
+        else:
+            num_cams = 1
+        if self.use_grid_mask:
+            img = self.grid_mask(img)
+        img = img.contiguous(memory_format=torch.channels_last)
+        with torch.autocast("cuda", dtype=self.encoder_dtype, enabled=img.is_cuda and self.encoder_dtype != torch.float32):
+            levels = self.img_backbone(img)
+            if self.img_neck is not None:
+                levels = self.img_neck(levels)
+        levels = [f.float().reshape((bs, num_cams) + f.shape[1:]) for f in levels]
+        depths = None
+        if return_depth and self.depth_branch is not None:
+            depths = self.depth_branch(levels, None if metas is None else metas.get("focal"))
+        feature_maps = feature_maps_format(levels)
+        feature_maps[0] = shared_feature_grad(feature_maps[0])
+        return (feature_maps, depths) if return_depth else feature_maps
+
+    def forward(self, img, **data):
+        return self.forward_train(img, **data) if self.training else self.forward_test(img, **data)
+
+    def forward_train(self, img, **data):
+        feature_maps, depths = self.extract_feat(img, True, data)
+        model_outs = self.head(img, feature_maps, data)
+        output = self.head.loss(model_outs, data)
+        if depths is not None and "gt_depth" in data:
+            output["loss_dense_depth"] = self.depth_branch.loss(depths, data["gt_depth"])
+        return output
+
+    def forward_test(self, img, **data):
+        if isinstance(img, list):  # single "augmentation"
+            data = {k: (v[0] if isinstance(v, list) else v) for k, v in data.items()}
+            img = img[0]
+        return self.simple_test(img, **data)
+
+    def simple_test(self, img, **data):
+        feature_maps = self.extract_feat(img)
+        model_outs = self.head(img, feature_maps, data)
+        results = self.head.post_process(model_outs, data)
+        return [dict(img_bbox=r) for r in results]

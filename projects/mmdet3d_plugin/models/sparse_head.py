@@ -1,0 +1,33 @@
+"""Head dispatcher (registered name ``SparseHead``, reference models/sparse_head.py:14-110): the HiP-AD
+configs run a single unified decoder (``task_config = dict(with_onedecoder=True)``); the legacy
+per-task heads of the reference are not part of the hot path."""
+from hipad_amd.compat import HEADS, BaseModule, build_from_cfg
+
+__all__ = ["SparseHead"]
+
+
+@HEADS.register_module()
+class SparseHead(BaseModule):
+    def __init__(self, task_config: dict, init_cfg=None, det_head=None, map_head=None, motion_plan_head=None,
+                 onedecoder_head=None, evaluate_bench2dive=False, **kwargs):
+        super().__init__(init_cfg)
+        self.task_config = task_config
+        for legacy in ("with_det", "with_map", "with_motion_plan"):
+            if task_config.get(legacy, False):
+                raise NotImplementedError(f"task_config[{legacy!r}]: the per-task heads are outside the hot path")
+        if not task_config.get("with_onedecoder", False):
+            raise ValueError("SparseHead needs task_config['with_onedecoder'] = True")
+        self.onedecoder_head = build_from_cfg(onedecoder_head, HEADS)
+        self.evaluate_bench2dive = evaluate_bench2dive
+
+    def init_weights(self):
+        self.onedecoder_head.init_weights()
+
+    def forward(self, img, feature_maps, metas: dict):
+        return self.onedecoder_head(img, feature_maps, metas)
+
+    def loss(self, model_outs, data):
+        return self.onedecoder_head.loss(*model_outs, data)
+
+    def post_process(self, model_outs, data):
+        return self.onedecoder_head.post_process(*model_outs, data)

@@ -280,7 +280,87 @@ def gen_keypoints_and_dfa():
     save("dfa_modules", **out)
 
 
-GENS = {"daf": gen_daf, "format": gen_format, "project": gen_project, "dfa": gen_keypoints_and_dfa}
+def gen_decoder():
+    """Whole SparseOneDecoder, reference class, stage-2 config, 2 temporal frames on a small pyramid.
+
+    The two substitutions SURVEY.md section 8c defines for a CPU run of the reference decoder:
+    blocks.DAF <- the reference's own torch gather with the CUDA border mask (ref_daf above) and
+    FlashAttention.forward <- fp32 softmax(QK^T/sqrt(D))V (flash-attn is not installed)."""
+    import copy
+    import math
+    from types import SimpleNamespace
+    from seeded import seeded, checksum, fill_parameters_by_name
+    ref_attn = S.ref_import("models.attention")
+    S.ref_import("models.separate_attn")
+    S.ref_import("models.instance_bank")
+    S.ref_import("models.plan.instance_bank"); S.ref_import("models.ego.instance_bank")
+    S.ref_import("models.plan.blocks"); S.ref_import("models.ego.blocks"); S.ref_import("models.motion.blocks")
+    ref_dec = S.ref_import("models.sparse_onedecoder")
+
+    def sdpa_forward(self, q, kv, causal=False, key_padding_mask=None):
+        q, kv = q.float(), kv.float()
+        k, v = kv[:, :, 0], kv[:, :, 1]
+        att = torch.einsum("bqhd,bkhd->bhqk", q, k) / math.sqrt(q.shape[-1])
+        return torch.einsum("bhqk,bkhd->bqhd", att.softmax(-1), v), None
+
+    ref_attn.FlashAttention.forward = sdpa_forward
+
+    def patched_daf(col_feats, spatial_shape, scale_start_index, points_2d, weights):
+        return ref_daf(col_feats, spatial_shape, scale_start_index, points_2d, weights, weights.shape[-1])
+
+    ref_blocks.DAF = patched_daf
+    hw = (128, 352)  # quarter-size input keeps the CPU run and the fixture small
+    _, od, ns = dfa_cfgs()
+    txt = cfg_text().replace('"/opt/data/private/project/HiP-AD"', repr(S.REF)).replace(
+        "input_shape = (640, 352)", f"input_shape = ({hw[1]}, {hw[0]})")
+    ns = {}
+    exec(compile(txt, "hipad_b2d_stage2.py", "exec"), ns)
+    od = copy.deepcopy(ns["model"]["head"]["onedecoder_head"])
+    od.pop("type")
+    for k in list(od):
+        if k.startswith("loss_") or k.endswith("_sampler") or (k.endswith("_decoder") and k != "num_single_frame_decoder"):
+            od[k] = None
+    dec = ref_dec.SparseOneDecoder(**od)
+    dec.det_sampler = dec.map_sampler = SimpleNamespace(dn_metas=None)
+    dec.det_decoder = SimpleNamespace(score_threshold=None)
+    dec.init_weights()
+    psum = fill_parameters_by_name(dec, 4242)
+    dec.eval()
+    shapes = syn.pyramid_shapes(hw)
+    pm, wh = syn.projection_mats(hw, bs=1)
+    out = dict(input_hw=np.array(hw), param_checksum=psum,
+               state_keys=np.array(list(dec.state_dict().keys())),
+               state_shapes=np.array([str(tuple(v.shape)) for v in dec.state_dict().values()]))
+    for step in range(2):
+        maps = [seeded((1, 6, 256, h, w), 800 + 10 * step + i, 0.5) for i, (h, w) in enumerate(shapes)]
+        fm = ref_ops.feature_maps_format(maps)
+        T = syn.ego_motion(step)
+        metas = dict(projection_mat=torch.from_numpy(pm), image_wh=torch.from_numpy(wh),
+                     timestamp=torch.tensor([0.5 * step], dtype=torch.float64),
+                     img_metas=[dict(T_global=T, T_global_inv=np.linalg.inv(T))],
+                     gt_ego_fut_cmd=torch.tensor([[0, 0, 0, 1, 0, 0]], dtype=torch.float32),
+                     target_point=torch.tensor([[3.0, 25.0]]))
+        with torch.no_grad():
+            det, mp, ego, plan, motion, _ = dec(None, fm, metas)
+        print("step", step, "tokens", dec.total_num_anchor, "temp", dec.total_num_temp_anchor)
+        for li in (0, 5):
+            out[f"s{step}_det_cls_{li}"] = det["classification"][li]
+            out[f"s{step}_det_box_{li}"] = det["prediction"][li]
+            out[f"s{step}_det_qt_{li}"] = det["quality"][li]
+            out[f"s{step}_map_cls_{li}"] = mp["classification"][li]
+            out[f"s{step}_map_pts_{li}"] = mp["prediction"][li]
+            out[f"s{step}_plan_cls_{li}"] = plan["classification"][li]
+            out[f"s{step}_plan_reg_{li}"] = plan["prediction"][li]
+            out[f"s{step}_ego_status_{li}"] = ego["status"][li]
+            out[f"s{step}_motion_cls_{li}"] = motion["classification"][li]
+        out[f"s{step}_motion_reg_5"] = motion["prediction"][5][:, ::9]
+        out[f"s{step}_det_feature"] = det["instance_feature"][:, ::9]
+        out[f"s{step}_num_temp"] = np.array(dec.total_num_temp_anchor)
+    save("decoder_stage2", **out)
+
+
+GENS = {"daf": gen_daf, "format": gen_format, "project": gen_project, "dfa": gen_keypoints_and_dfa,
+        "decoder": gen_decoder}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -29,3 +29,21 @@ def fill_parameters(module, seed_base, scale=0.08):
             p.copy_(seeded(tuple(p.shape), seed_base + i, scale))
             sums.append(checksum(p))
     return torch.stack(sums).sum(0)
+
+
+def fill_parameters_by_name(module, seed_base, scale=0.05):
+    """Seed every trainable parameter from a hash of its NAME (independent of construction order):
+    matrices ~ N(0, scale), vectors (biases, norm weights) ~ N(0, scale) + (1 for *norm* weights)."""
+    import zlib
+    total = torch.zeros(3, dtype=torch.float64)
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if not p.requires_grad:
+                continue
+            seed = (zlib.crc32(name.encode()) + seed_base) % (2 ** 31)
+            val = seeded(tuple(p.shape), seed, scale)
+            if p.dim() == 1 and name.endswith("weight"):
+                val = val + 1.0  # LayerNorm / BatchNorm / Scale gains stay near one
+            p.copy_(val)
+            total += checksum(p)
+    return total

@@ -1,0 +1,114 @@
+"""Whole unified decoder against the reference's SparseOneDecoder (tests/golden/decoder_stage2.npz:
+reference class, stage-2 config, seeded parameters, two temporal frames; see make_golden.gen_decoder).
+
+CPU: configs build the same model dict, module tree has the reference's state_dict keys and shapes
+(checkpoint compatibility).  GPU: numerical parity of every head output on both frames."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from seeded import fill_parameters_by_name, seeded
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_CFG = "/root/reference/projects/configs/hipad_b2d_stage{}.py"
+
+
+def build_decoder(hw):
+    import projects.mmdet3d_plugin.models  # noqa: F401  (registers everything)
+    from hipad_amd.compat import HEADS, Config, build_from_cfg
+    from projects.configs._hipad_b2d_common import hipad_b2d
+    cfg = hipad_b2d(stage=2, input_shape=(hw[1], hw[0]))
+    dec = build_from_cfg(cfg["model"]["head"]["onedecoder_head"], HEADS)
+    dec.init_weights()
+    return dec
+
+
+def test_state_dict_matches_reference_decoder(golden):
+    z = golden("decoder_stage2")
+    dec = build_decoder(tuple(z["input_hw"]))
+    mine = {k: str(tuple(v.shape)) for k, v in dec.state_dict().items()}
+    ref = dict(zip(z["state_keys"].tolist(), z["state_shapes"].tolist()))
+    assert set(mine) == set(ref), (sorted(set(ref) - set(mine))[:8], sorted(set(mine) - set(ref))[:8])
+    assert all(mine[k] == ref[k] for k in ref)
+    n = sum(p.numel() for p in dec.parameters())
+    assert abs(n - 70.81e6) < 0.02e6  # 70.81 M parameters
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CFG.format(2)), reason="reference tree not present (GPU box)")
+@pytest.mark.parametrize("stage", [1, 2])
+def test_config_model_dict_equals_reference(stage):
+    from hipad_amd.compat import Config
+    ns = {}
+    exec(compile(open(REF_CFG.format(stage)).read(), "ref_cfg", "exec"), ns)
+    mine = Config.fromfile(os.path.join(ROOT, f"projects/configs/hipad_b2d_stage{stage}.py"))
+
+    def norm(o, root):
+        if isinstance(o, dict):
+            return {str(k): norm(v, root) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [norm(v, root) for v in o]
+        return o.replace(root, "<P>") if isinstance(o, str) else o
+
+    assert norm(ns["model"], ns["project_dir"]) == norm(dict(mine["model"]), mine["project_dir"])
+
+
+def run_two_frames(dec, z, device):
+    from hipad_amd import synthetic as syn
+    from projects.mmdet3d_plugin.ops import feature_maps_format
+    hw = tuple(int(v) for v in z["input_hw"])
+    shapes = syn.pyramid_shapes(hw)
+    pm, wh = syn.projection_mats(hw, bs=1)
+    outs = []
+    for step in range(2):
+        maps = [seeded((1, 6, 256, h, w), 800 + 10 * step + i, 0.5).to(device) for i, (h, w) in enumerate(shapes)]
+        fm = feature_maps_format(maps)
+        T = syn.ego_motion(step)
+        metas = dict(projection_mat=torch.from_numpy(pm).to(device), image_wh=torch.from_numpy(wh).to(device),
+                     timestamp=torch.tensor([0.5 * step], dtype=torch.float64, device=device),
+                     img_metas=[dict(T_global=T, T_global_inv=np.linalg.inv(T))],
+                     gt_ego_fut_cmd=torch.tensor([[0, 0, 0, 1, 0, 0]], dtype=torch.float32, device=device),
+                     target_point=torch.tensor([[3.0, 25.0]], device=device))
+        with torch.no_grad():
+            outs.append(dec(None, fm, metas))
+    return outs
+
+
+@pytest.mark.gpu
+def test_decoder_two_frames_match_reference(golden):
+    z = golden("decoder_stage2")
+    dec = build_decoder(tuple(z["input_hw"]))
+    got = fill_parameters_by_name(dec, 4242)
+    assert torch.allclose(got, torch.from_numpy(z["param_checksum"]), rtol=1e-9), "seeded parameters drifted"
+    dec = dec.cuda().eval()
+    outs = run_two_frames(dec, z, "cuda")
+    assert dec.total_num_anchor == 1481
+    worst = {}
+
+    def check(name, tensor, tol):
+        ref = z[name]
+        a = tensor.detach().float().cpu().numpy()
+        assert a.shape == ref.shape, (name, a.shape, ref.shape)
+        err = float(np.abs(a - ref).max() / max(1e-9, np.abs(ref).max()))
+        worst[name] = err
+        assert err < tol, (name, err)
+
+    for step, (det, mp, ego, plan, motion, _) in enumerate(outs):
+        assert int(z[f"s{step}_num_temp"]) == dec.total_num_temp_anchor if step == 1 else True
+        for li in (0, 5):
+            # attention runs on bf16 operands (as the reference's flash-attn does): 1e-2 class, looser
+            # after six layers of compounding and for the logit heads
+            tol = 1e-2 if li == 0 else 3e-2
+            check(f"s{step}_det_cls_{li}", det["classification"][li], tol)
+            check(f"s{step}_det_box_{li}", det["prediction"][li], tol)
+            check(f"s{step}_det_qt_{li}", det["quality"][li], tol)
+            check(f"s{step}_map_cls_{li}", mp["classification"][li], tol)
+            check(f"s{step}_map_pts_{li}", mp["prediction"][li], tol)
+            check(f"s{step}_plan_cls_{li}", plan["classification"][li], tol)
+            check(f"s{step}_plan_reg_{li}", plan["prediction"][li], tol)
+            check(f"s{step}_ego_status_{li}", ego["status"][li], tol)
+            check(f"s{step}_motion_cls_{li}", motion["classification"][li], tol)
+        check(f"s{step}_motion_reg_5", motion["prediction"][5][:, ::9], 3e-2)
+        check(f"s{step}_det_feature", det["instance_feature"][:, ::9], 3e-2)
+    print("worst relative errors:", {k: round(v, 5) for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]})
