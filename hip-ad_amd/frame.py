@@ -1,0 +1,120 @@
+"""One training frame of the whole hot path on synthetic data: multi-view images -> ResNet/FPN ->
+unified decoder -> objective -> backward -> optimiser step.  Shared by bench.py, smoke() and tests.
+
+The objective is a SURROGATE (mean square of every head output + the depth maps): the reference's
+target assignment and losses (sparse_onedecoder.py:1094-1579) are the first "next" row of SURVEY.md
+section 8f and not built yet.  It touches every head, so the backward runs through every kernel and
+every parameter the real losses would reach; the only work it leaves out is the loss arithmetic itself
+(and its host-side Hungarian matching).
+"""
+import numpy as np
+import torch
+
+from . import synthetic as syn
+
+
+def build_detector(stage=2, input_hw=(256, 704), plan_queries=None, device="cuda", with_cp=False):
+    import projects.mmdet3d_plugin.models  # noqa: F401  registers the modules
+    from hipad_amd.compat import DETECTORS, build_from_cfg
+    from projects.configs._hipad_b2d_common import hipad_b2d
+    cfg = hipad_b2d(stage=stage, input_shape=(input_hw[1], input_hw[0]))
+    model_cfg = cfg["model"]
+    model_cfg["img_backbone"]["pretrained"] = None  # no network / checkpoints here: random init
+    model_cfg["img_backbone"]["with_cp"] = with_cp
+    if plan_queries == 48 and stage == 2:
+        # BASELINE.json words the plan set as 6x8 = 48 queries: keep one anchor group of the ten
+        od = model_cfg["head"]["onedecoder_head"]
+        keep = od["plan_anchor_refer"]
+        for key in ("plan_instance_bank", "plan_refine_layer", "plan_decoder"):
+            od[key]["anchor_types"] = [keep]
+        od["plan_instance_bank"]["anchor_paths"] = {keep: od["plan_instance_bank"]["anchor_paths"][keep]}
+    model = build_from_cfg(model_cfg, DETECTORS)
+    model.init_weights()
+    return model.to(device), cfg
+
+
+class SyntheticFrames:
+    """Endless stream of synthetic frames with consistent ego motion (SURVEY.md section 8d inputs)."""
+
+    def __init__(self, bs=1, input_hw=(256, 704), device="cuda", seed=0):
+        self.bs, self.hw, self.device = bs, input_hw, device
+        self.gen = torch.Generator(device="cpu").manual_seed(seed)
+        pm, wh = syn.projection_mats(input_hw, bs=bs)
+        self.projection_mat = torch.from_numpy(pm).to(device)
+        self.image_wh = torch.from_numpy(wh).to(device)
+        self.step = 0
+        # a small pool of pre-generated images resident in HBM (the timed region starts with inputs on device)
+        self.pool = [torch.randn(bs, 6, 3, input_hw[0], input_hw[1], generator=self.gen).to(device) for _ in range(4)]
+        cmd = torch.zeros(bs, 6)
+        cmd[:, 3] = 1
+        self.cmd = cmd.to(device)
+        self.target = (torch.rand(bs, 2, generator=self.gen) * 60 - 30).to(device)
+
+    def next(self):
+        k = self.step
+        T = syn.ego_motion(k)
+        Tinv = np.linalg.inv(T)
+        data = dict(projection_mat=self.projection_mat, image_wh=self.image_wh,
+                    timestamp=torch.full((self.bs,), 0.5 * k, dtype=torch.float64, device=self.device),
+                    img_metas=[dict(T_global=T, T_global_inv=Tinv) for _ in range(self.bs)],
+                    gt_ego_fut_cmd=self.cmd, target_point=self.target)
+        self.step += 1
+        return self.pool[k % len(self.pool)], data
+
+
+def surrogate_objective(model_outs, depths=None):
+    det, mp, ego, plan, motion, _ = model_outs
+    terms = []
+    for out in (det, mp, ego, plan, motion):
+        for key in ("classification", "prediction", "quality", "status"):
+            for t in out.get(key, []) or []:
+                if t is not None:
+                    terms.append(t.float().square().mean())
+    for d in depths or []:
+        terms.append(d.float().clamp(max=60.0).mean() * 1e-3)
+    return torch.stack(terms).sum()
+
+
+class TrainStep:
+    """forward + objective + backward + gradient all-reduce + clip + AdamW step for one frame batch
+    (optimiser settings of the reference: AdamW lr 2e-4 wd 1e-3, backbone lr x0.5, grad-clip 25,
+    projects/configs/hipad_b2d_stage2.py:629-641; data parallel as apis/mmdet_train.py:97-102)."""
+
+    def __init__(self, model, cfg, comm_dtype=None):
+        from .dist import FlatGrads, broadcast_parameters
+        self.model = model
+        broadcast_parameters(model)
+        opt = cfg["optimizer"]
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        bb = [p for n, p in named if n.startswith("img_backbone")]
+        rest = [p for n, p in named if not n.startswith("img_backbone")]
+        mult = opt["paramwise_cfg"]["custom_keys"]["img_backbone"]["lr_mult"]
+        self.params = rest + bb
+        self.grads = FlatGrads(self.params, comm_dtype=comm_dtype)
+        self.opt = torch.optim.AdamW([dict(params=rest, lr=opt["lr"]), dict(params=bb, lr=opt["lr"] * mult)],
+                                     lr=opt["lr"], weight_decay=opt["weight_decay"], fused=True)
+        self.max_norm = cfg["optimizer_config"]["grad_clip"]["max_norm"]
+
+    def forward_backward(self, img, data):
+        loss = _frame_loss(self.model, img, data)
+        loss.backward()
+        return loss
+
+    def __call__(self, img, data):
+        self.grads.zero()
+        loss = self.forward_backward(img, data)
+        self.grads.check_views()
+        self.grads.all_reduce_mean()
+        torch.nn.utils.clip_grad_norm_(self.params, self.max_norm, foreach=True)
+        self.opt.step()
+        return loss
+
+
+DECODER_DTYPE = torch.bfloat16  # GEMMs of the decoder under autocast (norms / softmax / kernels stay fp32)
+
+
+def _frame_loss(det, img, data):
+    feature_maps, depths = det.extract_feat(img, True, data)
+    with torch.autocast("cuda", dtype=DECODER_DTYPE, enabled=DECODER_DTYPE != torch.float32):
+        outs = det.head(img, feature_maps, data)
+    return surrogate_objective(outs, depths)

@@ -82,15 +82,29 @@ class SparsePlanAlignRefinementModule(BaseModule):
             for area in self.speed_areas:
                 same_area = [c for c, t in zip(chunks, self.anchor_types) if t[0] == "speed" and t[2] == area]
                 speed_query[area] = aligned + sum(same_area)
+        # The reference evaluates one (regression, score) pair per anchor type; many of those calls
+        # repeat the same module on the same input (the score head of all temp/spat groups, both heads
+        # of the speed groups that share an interval).  Evaluate every distinct (module, input) once and
+        # stack the inputs of a shared module into one call.
+        areas = list(speed_query)
+        cache = {}
+
+        def run(module, key, sources):
+            if (id(module), key) not in cache:
+                out = module(torch.cat(sources, dim=1) if len(sources) > 1 else sources[0])
+                cache[(id(module), key)] = out.chunk(len(sources), dim=1)
+            return cache[(id(module), key)]
+
         regs, scores = [], []
         for t in self.anchor_types:
             branch = getattr(self, f"plan_reg_branch_{t[0]}_{t[1]}")
             if t[0] in ("temp", "spat"):
-                src, head = aligned, self.plan_cls_branch
+                regs.append(run(branch, "aligned", [aligned])[0])
+                scores.append(run(self.plan_cls_branch, "aligned", [aligned])[0])
             elif t[0] == "speed":
-                src, head = speed_query[t[2]], self.plan_cls_branch_speed
+                i = areas.index(t[2])
+                regs.append(run(branch, "speed", [speed_query[a] for a in areas])[i])
+                scores.append(run(self.plan_cls_branch_speed, "speed", [speed_query[a] for a in areas])[i])
             else:
                 raise NotImplementedError(t[0])
-            regs.append(branch(src))
-            scores.append(head(src))
         return torch.cat(regs, dim=1) + anchor, torch.cat(scores, dim=1)
