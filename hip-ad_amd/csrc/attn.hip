@@ -64,7 +64,12 @@ struct AttnArgs {
   float scale;           // softmax scale
   uint32_t seed, drop_thresh;
   float inv_keep;        // 1 / (1 - p_drop)
+  const uint32_t *seed_dev;  // optional device-resident step counter added to seed (graph replay)
 };
+
+__device__ __forceinline__ uint32_t eff_seed(const AttnArgs &a) {
+  return a.seed_dev ? a.seed + *a.seed_dev * 0x9E3779B9u : a.seed;
+}
 
 constexpr float kNegInf = -INFINITY;
 
@@ -80,6 +85,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(float *__restrict__ out, 
   __shared__ float s_m[4][16], s_l[4][16];
   __shared__ float s_o[4][64][DC16 * 4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t seed = a.drop_thresh ? eff_seed(a) : 0u;
   const int l15 = lane & 15, quad = lane >> 4;
   const int q0 = blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
   const int qi = min(q0 + l15, a.Nq - 1);
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(float *__restrict__ out, 
         psum += p;
         if (a.drop_thresh) {
           const int key = k0 + 16 * t + 4 * quad + r;
-          p = keep_prob(a.seed, b, h, q0 + l15, key, a.drop_thresh) ? p * a.inv_keep : 0.f;
+          p = keep_prob(seed, b, h, q0 + l15, key, a.drop_thresh) ? p * a.inv_keep : 0.f;
         }
         pf[4 * t + r] = f2bf(p);
       }
@@ -231,6 +237,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(float *__restrict__ dq
   constexpr int DC32 = D / 32, DC16 = D / 16;
   __shared__ float s_o[4][64][DC16 * 4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t seed = a.drop_thresh ? eff_seed(a) : 0u;
   const int l15 = lane & 15, quad = lane >> 4;
   const int q0 = blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
   const int qi = min(q0 + l15, a.Nq - 1);
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(float *__restrict__ dq
         float p = (key < a.Nk) ? exp2f(s[r] * a.scale_log2e - my_lse) : 0.f;
         float dpr = dp[r];
         if (a.drop_thresh) {
-          const bool keep = keep_prob(a.seed, b, h, q0 + l15, key, a.drop_thresh);
+          const bool keep = keep_prob(seed, b, h, q0 + l15, key, a.drop_thresh);
           dpr = keep ? dpr * a.inv_keep : 0.f;  // d(dropped P)/dP
         }
         dsf[4 * t + r] = f2bf(p * (dpr - my_delta) * a.scale);
@@ -324,6 +331,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(float *__restrict__ d
   __shared__ float s_k[4][64][DC16 * 4];
   __shared__ float s_v[4][64][DC16 * 4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t seed = a.drop_thresh ? eff_seed(a) : 0u;
   const int l15 = lane & 15, quad = lane >> 4;
   const int kk0 = blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
   const int ki = min(kk0 + l15, a.Nk - 1);
@@ -370,7 +378,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(float *__restrict__ d
         float p = ok ? exp2f(s[r] * a.scale_log2e - lse_b[qc]) : 0.f;
         float pd = p, dpr = dp[r];
         if (a.drop_thresh) {
-          const bool keep = keep_prob(a.seed, b, h, qi, kk0 + l15, a.drop_thresh);
+          const bool keep = keep_prob(seed, b, h, qi, kk0 + l15, a.drop_thresh);
           pd = keep ? p * a.inv_keep : 0.f;
           dpr = keep ? dpr * a.inv_keep : 0.f;
         }
@@ -417,12 +425,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(float *__restrict__ d
   }
 }
 
-static AttnArgs make_args(int B, int H, int Nq, int Nk, int D, float scale, float p_drop, uint32_t seed) {
+static AttnArgs make_args(int B, int H, int Nq, int Nk, int D, float scale, float p_drop, uint32_t seed,
+                          const uint32_t *seed_dev) {
   AttnArgs a;
   a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.ld = H * D;
   a.scale = scale;
   a.scale_log2e = scale * 1.4426950408889634f;
   a.seed = seed;
+  a.seed_dev = seed_dev;
   if (p_drop > 0.f) {
     double t = (double)p_drop * 4294967296.0;
     a.drop_thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
@@ -451,11 +461,11 @@ extern "C" {
 
 int hipad_attention_forward(float *out, float *lse, const float *q, const float *k, const float *v, int B,
                             int H, int Nq, int Nk, int D, float softmax_scale, float p_drop, unsigned seed,
-                            hipad_stream_t stream_) {
+                            const unsigned *seed_dev, hipad_stream_t stream_) {
   int rc = attn_check(B, H, Nq, Nk, D, p_drop);
   if (rc != HIPAD_OK) return rc;
   if (!out || !q || !k || !v) return HIPAD_EINVAL;
-  const AttnArgs a = make_args(B, H, Nq, Nk, D, softmax_scale, p_drop, seed);
+  const AttnArgs a = make_args(B, H, Nq, Nk, D, softmax_scale, p_drop, seed, seed_dev);
   const dim3 grid((Nq + 15) / 16, H, B), block(256);
   hipStream_t stream = (hipStream_t)stream_;
   if (D == 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, block, 0, stream, out, lse, q, k, v, a);
@@ -466,11 +476,12 @@ int hipad_attention_forward(float *out, float *lse, const float *q, const float 
 
 int hipad_attention_backward(float *dq, float *dk, float *dv, float *delta_ws, const float *dout, const float *out,
                              const float *lse, const float *q, const float *k, const float *v, int B, int H, int Nq,
-                             int Nk, int D, float softmax_scale, float p_drop, unsigned seed, hipad_stream_t stream_) {
+                             int Nk, int D, float softmax_scale, float p_drop, unsigned seed, const unsigned *seed_dev,
+                             hipad_stream_t stream_) {
   int rc = attn_check(B, H, Nq, Nk, D, p_drop);
   if (rc != HIPAD_OK) return rc;
   if (!dq || !dk || !dv || !delta_ws || !dout || !out || !lse || !q || !k || !v) return HIPAD_EINVAL;
-  const AttnArgs a = make_args(B, H, Nq, Nk, D, softmax_scale, p_drop, seed);
+  const AttnArgs a = make_args(B, H, Nq, Nk, D, softmax_scale, p_drop, seed, seed_dev);
   hipStream_t stream = (hipStream_t)stream_;
   const long nd = (long)B * Nq * H;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, stream, delta_ws, dout, out,

@@ -80,7 +80,7 @@ class TrainStep:
     (optimiser settings of the reference: AdamW lr 2e-4 wd 1e-3, backbone lr x0.5, grad-clip 25,
     projects/configs/hipad_b2d_stage2.py:629-641; data parallel as apis/mmdet_train.py:97-102)."""
 
-    def __init__(self, model, cfg, comm_dtype=None):
+    def __init__(self, model, cfg, comm_dtype=None, capturable=False):
         from .dist import FlatGrads, broadcast_parameters
         self.model = model
         broadcast_parameters(model)
@@ -92,7 +92,7 @@ class TrainStep:
         self.params = rest + bb
         self.grads = FlatGrads(self.params, comm_dtype=comm_dtype)
         self.opt = torch.optim.AdamW([dict(params=rest, lr=opt["lr"]), dict(params=bb, lr=opt["lr"] * mult)],
-                                     lr=opt["lr"], weight_decay=opt["weight_decay"], fused=True)
+                                     lr=opt["lr"], weight_decay=opt["weight_decay"], fused=True, capturable=capturable)
         self.max_norm = cfg["optimizer_config"]["grad_clip"]["max_norm"]
 
     def forward_backward(self, img, data):
@@ -100,14 +100,127 @@ class TrainStep:
         loss.backward()
         return loss
 
+    def update(self):
+        torch.nn.utils.clip_grad_norm_(self.params, self.max_norm, foreach=True)
+        self.opt.step()
+
     def __call__(self, img, data):
+        from . import functional as HF
         self.grads.zero()
         loss = self.forward_backward(img, data)
         self.grads.check_views()
         self.grads.all_reduce_mean()
-        torch.nn.utils.clip_grad_norm_(self.params, self.max_norm, foreach=True)
-        self.opt.step()
+        self.update()
+        HF.advance_dropout_clock(img.device)
         return loss
+
+
+class GraphedTrainStep:
+    """The same step replayed from hipGraphs: a frame is ~17 000 small kernels, and launching them
+    eagerly costs more host time than the GPU needs to run them.
+
+    Everything the step reads that changes from frame to frame lives in static device buffers filled
+    OUTSIDE the graph (images, timestamp, ego-motion transform, GridMask parameters; the dropout clock
+    and the instance-bank caches are device state updated in place INSIDE it), so the captured work has
+    no host dependency.  Graph A = zero grads + forward + objective + backward; the gradient
+    all-reduce runs eagerly between A and B when there is more than one rank; graph B = clip + AdamW.
+    Tracking-id bookkeeping (InstanceBank.get_instance_id: data-dependent shapes, inference only) is
+    left out of the captured step.
+    """
+
+    def __init__(self, model, cfg, frames, comm_dtype=None, warm_frames=3):
+        import torch.distributed as dist
+        self.model, self.frames = model, frames
+        self.inner = TrainStep(model, cfg, comm_dtype=comm_dtype, capturable=True)
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        dec = model.head.onedecoder_head
+        dec.with_instance_id = False
+        if model.use_grid_mask:
+            model.grid_mask.external_randomize = True
+        dev = frames.device
+        bs = frames.bs
+        img, data = frames.next()
+        self.img = torch.empty_like(img)
+        self.ts = torch.zeros(bs, dtype=torch.float64, device=dev)
+        self.T = torch.zeros(bs, 4, 4, dtype=torch.float32, device=dev)
+        self._T_host = torch.zeros(bs, 4, 4, dtype=torch.float32).pin_memory()
+        self._ts_host = torch.zeros(bs, dtype=torch.float64).pin_memory()
+        self.data = dict(projection_mat=data["projection_mat"], image_wh=data["image_wh"], timestamp=self.ts,
+                         T_temp2cur=self.T, img_metas=data["img_metas"], gt_ego_fut_cmd=data["gt_ego_fut_cmd"],
+                         target_point=data["target_point"])
+        self._prev_T = None
+        self._feed(img, data)
+        # cold frames (no temporal cache yet) run eagerly; they also size every workspace / cache
+        if model.use_grid_mask:
+            model.grid_mask.external_randomize = False
+            model.grid_mask.train()
+        for i in range(warm_frames):
+            if i:
+                self._feed(*frames.next())
+            self._eager_body()
+        if model.use_grid_mask:
+            model.grid_mask.external_randomize = True
+        torch.cuda.synchronize()
+        self._feed(*frames.next())
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # one more eager pass on the capture-side stream (library workspaces)
+            self._eager_body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._feed(*frames.next())
+        self.graph_a = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_a):
+            self.loss = self._fwd_bwd()
+        self.graph_b = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+            self._update()
+        # the capture itself did not execute the work: replay once so the banks hold this frame's state
+        self.graph_a.replay()
+        self.inner.grads.all_reduce_mean()
+        self.graph_b.replay()
+
+    def _feed(self, img, data):
+        import numpy as np
+        self.img.copy_(img, non_blocking=True)
+        Ts = [m["T_global"] for m in data["img_metas"]]
+        Tinv = [m["T_global_inv"] for m in data["img_metas"]]
+        prev = self._prev_T if self._prev_T is not None else Ts
+        self._T_host.copy_(torch.from_numpy(np.stack([ti @ tp for ti, tp in zip(Tinv, prev)]).astype(np.float32)))
+        self._prev_T = Ts
+        self._ts_host.copy_(data["timestamp"].cpu() if data["timestamp"].is_cuda is False else self._ts_from(data))
+        self.T.copy_(self._T_host, non_blocking=True)
+        self.ts.copy_(self._ts_host, non_blocking=True)
+        if self.model.use_grid_mask and getattr(self.model.grid_mask, "_last_h", None) is not None:
+            self.model.grid_mask.randomize(self.img.device)
+
+    def _ts_from(self, data):
+        return torch.full((self.frames.bs,), 0.5 * (self.frames.step - 1), dtype=torch.float64)
+
+    def _fwd_bwd(self):
+        self.inner.grads.zero()
+        loss = _frame_loss(self.model, self.img, self.data)
+        loss.backward()
+        return loss
+
+    def _update(self):
+        from . import functional as HF
+        self.inner.update()
+        HF.advance_dropout_clock(self.img.device)
+
+    def _eager_body(self):
+        self._fwd_bwd()
+        self.inner.grads.check_views()
+        self.inner.grads.all_reduce_mean()
+        self._update()
+
+    def __call__(self):
+        self._feed(*self.frames.next())
+        self.graph_a.replay()
+        if self.world > 1:
+            self.inner.grads.all_reduce_mean()
+        self.graph_b.replay()
+        return self.loss
 
 
 DECODER_DTYPE = torch.bfloat16  # GEMMs of the decoder under autocast (norms / softmax / kernels stay fp32)

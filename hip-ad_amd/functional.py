@@ -66,29 +66,55 @@ def sampling_weights(u, v, keep, L, P, G):
     return _SamplingWeights.apply(u, v, keep, L, P, G)
 
 
+_DROPOUT_CLOCK = {}
+_CALL_SITE = [0]
+
+
+def dropout_clock(device):
+    """Device-resident int32 step counter mixed into the attention dropout seed.  ``advance`` it once
+    per training step (an in-place add: capturable), so a replayed graph draws fresh masks."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    t = _DROPOUT_CLOCK.get(key)
+    if t is None:
+        t = _DROPOUT_CLOCK[key] = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", key))
+    return t
+
+
+def advance_dropout_clock(device):
+    dropout_clock(device).add_(1)
+
+
+def new_call_site_seed():
+    """A distinct constant per attention module, so modules draw different masks at the same step."""
+    _CALL_SITE[0] += 1
+    return (_CALL_SITE[0] * 2654435761) & 0x7FFFFFFF
+
+
 class _Attention(Function):
     @staticmethod
     def forward(ctx, q, k, v, heads, scale, p_drop, seed):
         q, k, v = _c32(q), _c32(k), _c32(v)
         need = any(ctx.needs_input_grad[:3])
-        out, lse = _lib.attention_forward(q, k, v, heads, scale, p_drop, seed, need_lse=need)
+        clock = dropout_clock(q.device) if p_drop > 0.0 else None
+        out, lse = _lib.attention_forward(q, k, v, heads, scale, p_drop, seed, need_lse=need, seed_dev=clock)
         if need:
             ctx.save_for_backward(q, k, v, out, lse)
         ctx.cfg = (heads, scale, p_drop, seed)
+        ctx.clock = clock
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
         q, k, v, out, lse = ctx.saved_tensors
-        dq, dk, dv = _lib.attention_backward(_c32(dout), out, lse, q, k, v, *ctx.cfg)
+        dq, dk, dv = _lib.attention_backward(_c32(dout), out, lse, q, k, v, *ctx.cfg, seed_dev=ctx.clock)
         return dq, dk, dv, None, None, None, None
 
 
-def attention(q, k, v, heads, scale=None, p_drop=0.0, seed=None):
-    """softmax(q k^T * scale) v per head on (B, N, heads*D) tensors (see include/hipad.h)."""
+def attention(q, k, v, heads, scale=None, p_drop=0.0, seed=0):
+    """softmax(q k^T * scale) v per head on (B, N, heads*D) tensors (see include/hipad.h).  With
+    dropout the mask depends on (seed, dropout_clock): pass a per-module constant as ``seed`` and
+    advance the clock once per step."""
     if scale is None:
         scale = (q.shape[-1] // heads) ** -0.5
-    if p_drop > 0.0 and seed is None:
-        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
-    return _Attention.apply(q, k, v, heads, float(scale), float(p_drop), int(seed or 0))
+    return _Attention.apply(q, k, v, heads, float(scale), float(p_drop), int(seed))

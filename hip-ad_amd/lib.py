@@ -28,9 +28,9 @@ SIGNATURES = {
     "hipad_weights_softmax_forward": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
     "hipad_weights_softmax_backward": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p]),
     "hipad_attention_forward": (c_int, [c_void_p] * 5 + [c_int] * 5 + [ctypes.c_float, ctypes.c_float, ctypes.c_uint,
-                                                                     c_void_p]),
+                                                                     c_void_p, c_void_p]),
     "hipad_attention_backward": (c_int, [c_void_p] * 10 + [c_int] * 5 + [ctypes.c_float, ctypes.c_float,
-                                                                       ctypes.c_uint, c_void_p]),
+                                                                       ctypes.c_uint, c_void_p, c_void_p]),
 }
 
 _lib = None
@@ -240,7 +240,7 @@ def weights_softmax_backward(grad_w, stats, u, v, keep, L, P, G):
     return gu, gv
 
 
-def attention_forward(q, k, v, heads, scale, p_drop=0.0, seed=0, need_lse=True):
+def attention_forward(q, k, v, heads, scale, p_drop=0.0, seed=0, need_lse=True, seed_dev=None):
     """q (B,Nq,E), k/v (B,Nk,E), E = heads*D -> out (B,Nq,E), lse (B,heads,Nq) or None."""
     lib = load()
     _req(q, torch.float32, "q"); _req(k, torch.float32, "k"); _req(v, torch.float32, "v")
@@ -253,12 +253,12 @@ def attention_forward(q, k, v, heads, scale, p_drop=0.0, seed=0, need_lse=True):
     with torch.cuda.device(q.device):
         st = lib.hipad_attention_forward(out.data_ptr(), _ptr(lse), q.data_ptr(), k.data_ptr(), v.data_ptr(), B, heads,
                                          Nq, Nk, E // heads, float(scale), float(p_drop), int(seed) & 0xFFFFFFFF,
-                                         stream_ptr(q.device))
+                                         _ptr(seed_dev), stream_ptr(q.device))
     check(st, "hipad_attention_forward")
     return out, lse
 
 
-def attention_backward(dout, out, lse, q, k, v, heads, scale, p_drop=0.0, seed=0):
+def attention_backward(dout, out, lse, q, k, v, heads, scale, p_drop=0.0, seed=0, seed_dev=None):
     lib = load()
     _req(dout, torch.float32, "dout")
     B, Nq, E = q.shape
@@ -269,6 +269,6 @@ def attention_backward(dout, out, lse, q, k, v, heads, scale, p_drop=0.0, seed=0
         st = lib.hipad_attention_backward(dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), dout.data_ptr(),
                                           out.data_ptr(), lse.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), B,
                                           heads, Nq, Nk, E // heads, float(scale), float(p_drop),
-                                          int(seed) & 0xFFFFFFFF, stream_ptr(q.device))
+                                          int(seed) & 0xFFFFFFFF, _ptr(seed_dev), stream_ptr(q.device))
     check(st, "hipad_attention_backward")
     return dq, dk, dv

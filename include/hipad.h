@@ -168,16 +168,19 @@ int hipad_weights_softmax_backward(float *grad_u, float *grad_v, const float *gr
  *   matrix cores, fp32 softmax (the reference runs this block in fp16/bf16, attention.py:63).
  *   lse [B, H, Nq] f32: base-2 log-sum-exp of the scaled scores, needed by the backward (may be
  *   NULL for inference).  p_drop / seed: dropout on the probabilities (counter-based, the
- *   backward regenerates the same mask from the same seed).
+ *   backward regenerates the same mask from the same seed).  seed_dev (device pointer or NULL): a
+ *   step counter added to `seed` at run time, so a captured hipGraph draws a fresh mask per replay.
  * backward: dq [B,Nq,H*D], dk, dv [B,Nk,H*D] overwritten; delta_ws: B*H*Nq floats of scratch.
  * ---------------------------------------------------------------------------------- */
 int hipad_attention_forward(float *out, float *lse, const float *q, const float *k, const float *v,
                             int batch, int heads, int num_q, int num_k, int head_dim,
-                            float softmax_scale, float p_drop, unsigned seed, hipad_stream_t stream);
+                            float softmax_scale, float p_drop, unsigned seed, const unsigned *seed_dev,
+                            hipad_stream_t stream);
 int hipad_attention_backward(float *dq, float *dk, float *dv, float *delta_ws, const float *dout,
                              const float *out, const float *lse, const float *q, const float *k,
                              const float *v, int batch, int heads, int num_q, int num_k, int head_dim,
-                             float softmax_scale, float p_drop, unsigned seed, hipad_stream_t stream);
+                             float softmax_scale, float p_drop, unsigned seed, const unsigned *seed_dev,
+                            hipad_stream_t stream);
 
 /* Tuning knob (host side, process-wide): target number of (point, camera) pairs one
  * wavefront owns in the forward / backward kernels.  <=0 restores the default. */

@@ -37,6 +37,7 @@ class FlashMHA(nn.Module):
         if self.head_dim not in (32, 64, 128):
             raise ValueError(f"head_dim {self.head_dim} unsupported by the HIP attention kernel (32/64/128)")
         self.attention_dropout = attention_dropout
+        self._seed = HF.new_call_site_seed()
         self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
         self.in_proj_bias = nn.Parameter(torch.empty(3 * embed_dim)) if bias else None
         if not bias:
@@ -66,7 +67,8 @@ class FlashMHA(nn.Module):
             raise NotImplementedError("key_padding_mask is not used by the decoder")
         qp, kp, vp = self._project(q, k, v)
         p_drop = self.attention_dropout if self.training else 0.0
-        ctx = HF.attention(qp, kp, vp, self.num_heads, scale=1.0 / math.sqrt(self.head_dim), p_drop=p_drop)
+        ctx = HF.attention(qp, kp, vp, self.num_heads, scale=1.0 / math.sqrt(self.head_dim), p_drop=p_drop,
+                           seed=self._seed)
         return self.out_proj(ctx), None
 
 

@@ -161,9 +161,9 @@ class SparseBox3DKeyPointsGenerator(BaseModule):
             if dt is not None:
                 centre = centre - vel * dt.reshape(-1, 1, 1)
             centre = (T[..., :3, :3] @ centre[..., None]).squeeze(-1) + T[..., :3, 3]
-            cos_sin = (T[..., :2, :2] @ anchor[..., [COS_YAW, SIN_YAW], None]).squeeze(-1)
+            cos_sin = (T[..., :2, :2] @ torch.stack([anchor[..., COS_YAW], anchor[..., SIN_YAW]], dim=-1)[..., None]).squeeze(-1)
             vel = (T[..., :vdim, :vdim] @ vel[..., None]).squeeze(-1)
-            moved.append(torch.cat([centre, anchor[..., W:H + 1], cos_sin[..., [1, 0]], vel], dim=-1))
+            moved.append(torch.cat([centre, anchor[..., W:H + 1], cos_sin.flip(-1), vel], dim=-1))
         return moved
 
     @staticmethod

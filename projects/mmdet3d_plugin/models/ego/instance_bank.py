@@ -14,7 +14,7 @@ from hipad_amd.compat import PLUGIN_LAYERS, Linear, build_from_cfg
 from projects.mmdet3d_plugin.ops import feature_maps_format
 
 from ..blocks import linear_relu_ln
-from ..instance_bank import ego_motion_between
+from ..instance_bank import PersistentState, ego_motion_between
 from ..plan.instance_bank import front_view_encoder
 
 __all__ = ["EgoInstanceBank"]
@@ -29,7 +29,7 @@ def _ego_anchor(kind):
 
 
 @PLUGIN_LAYERS.register_module()
-class EgoInstanceBank(nn.Module):
+class EgoInstanceBank(PersistentState, nn.Module):
     def __init__(self, embed_dims, anchor_type="nus", anchor_handler=None, feature_map_scale=None,
                  num_temp_instances=0, anchor_grad=True, max_time_interval=2, num_anchor=None,
                  with_instance_feat=False, plan_anchor=None, feat_grad=True):
@@ -55,6 +55,7 @@ class EgoInstanceBank(nn.Module):
     def reset(self):
         self.cached_feature = self.cached_anchor = None
         self.metas = None
+        self._drop_state("feature", "anchor", "timestamp")
 
     def prepare_ego(self, batch_size, feature_maps):
         if self.with_instance_feat:
@@ -66,9 +67,11 @@ class EgoInstanceBank(nn.Module):
 
     def get(self, batch_size, metas, feature_maps, dn_metas=None):
         feature, anchor = self.prepare_ego(batch_size, feature_maps)
-        if self.cached_anchor is None or batch_size != self.cached_anchor.shape[0]:
+        if self._kept("anchor") is None or batch_size != self._kept("anchor").shape[0]:
             return feature, anchor, None, None
-        dt = (metas["timestamp"] - self.metas["timestamp"]).to(anchor.dtype)
+        # clones: the persistent buffers are overwritten in cache() before backward runs
+        self.cached_feature, self.cached_anchor = self._kept("feature").clone(), self._kept("anchor").clone()
+        dt = (metas["timestamp"] - self._kept("timestamp")).to(anchor.dtype)
         self.mask = dt.abs() <= self.max_time_interval
         if self.anchor_handler is not None:
             T = ego_motion_between(self.metas, metas, self.cached_anchor)
@@ -79,5 +82,6 @@ class EgoInstanceBank(nn.Module):
         if self.num_temp_instances <= 0:
             return
         self.metas = metas
-        self.cached_feature = instance_feature.detach()
-        self.cached_anchor = anchor.detach()
+        self.cached_feature = self._keep("feature", instance_feature)
+        self.cached_anchor = self._keep("anchor", anchor)
+        self._keep("timestamp", metas["timestamp"])

@@ -26,30 +26,50 @@ class GridMask(nn.Module):
     def set_prob(self, epoch, max_epoch):
         self.prob = self.st_prob * epoch / max_epoch
 
-    @staticmethod
-    def _stripes(length, canvas, d, ln, st, device):
-        """1 outside the zeroed stripes, for the centre crop of ``length`` out of ``canvas``."""
-        pos = torch.arange(length, device=device) + (canvas - length) // 2
-        k = torch.div(pos - st, d, rounding_mode="floor")
-        inside = (pos >= st) & (k < canvas // d) & ((pos - st) - k * d < ln)
-        return (~inside).float()
-
-    def forward(self, x):
-        if np.random.rand() > self.prob or not self.training:
-            return x
-        n, c, h, w = x.shape
-        hh, ww = int(1.5 * h), int(1.5 * w)
+    def randomize(self, device):
+        """Draw this step's mask parameters on the host (numpy RNG, like the reference) and ship them to
+        a 5-float device tensor [apply, d, l, st_h, st_w] with one asynchronous copy.  forward() only
+        reads that tensor, so it can sit inside a captured hipGraph while this runs outside."""
+        h = getattr(self, "_last_h", None)
+        if h is None:
+            raise RuntimeError("GridMask.randomize() needs one forward first (image height unknown)")
+        apply = float(np.random.rand() <= self.prob)
         d = np.random.randint(2, h)
         ln = min(max(int(d * self.ratio + 0.5), 1), d - 1)
         st_h, st_w = np.random.randint(d), np.random.randint(d)
-        np.random.randint(self.rotate)  # keep the host RNG stream aligned with the reference
+        np.random.randint(self.rotate)  # keeps the host RNG stream aligned with the reference
+        if getattr(self, "_host", None) is None:
+            self._host = torch.empty(5, dtype=torch.float32).pin_memory() if torch.cuda.is_available() else torch.empty(5)
+        self._host.copy_(torch.tensor([apply, d, ln, st_h, st_w], dtype=torch.float32))
+        if getattr(self, "_dev", None) is None or self._dev.device != torch.device(device):
+            self._dev = torch.empty(5, dtype=torch.float32, device=device)
+        self._dev.copy_(self._host, non_blocking=True)
+
+    @staticmethod
+    def _stripes(length, canvas, d, ln, st, device):
+        """1 outside the zeroed stripes, for the centre crop of ``length`` out of ``canvas`` (d, ln, st: 0-d tensors)."""
+        pos = torch.arange(length, device=device, dtype=torch.float32) + (canvas - length) // 2
+        k = torch.floor((pos - st) / d)
+        inside = (pos >= st) & (k < torch.floor(canvas / d)) & ((pos - st) - k * d < ln)
+        return (~inside).float()
+
+    def forward(self, x):
+        if not self.training:
+            return x
+        n, c, h, w = x.shape
+        self._last_h = h
+        if not getattr(self, "external_randomize", False):
+            self.randomize(x.device)
+        p = self._dev
+        apply, d, ln, st_h, st_w = p[0], p[1], p[2], p[3], p[4]
+        hh, ww = int(1.5 * h), int(1.5 * w)
         rows = self._stripes(h, hh, d, ln, st_h, x.device) if self.use_h else torch.ones(h, device=x.device)
         cols = self._stripes(w, ww, d, ln, st_w, x.device) if self.use_w else torch.ones(w, device=x.device)
         mask = rows[:, None] * cols[None, :]
         if self.mode == 1:
             mask = 1 - mask
-        mask = mask.to(x.dtype)
+        mask = torch.where(apply > 0, mask, torch.ones_like(mask)).to(x.dtype)  # not drawn this step: identity
         if self.offset:
-            noise = torch.from_numpy(2 * (np.random.rand(h, w) - 0.5)).to(x)
+            noise = torch.rand(h, w, device=x.device, dtype=x.dtype) * 2 - 1
             return x * mask + noise * (1 - mask)
         return x * mask

@@ -27,14 +27,41 @@ def select_topk(confidence, k, *tensors):
 
 
 def ego_motion_between(prev_metas, metas, like):
-    """(bs, 4, 4) transform taking coordinates of the cached frame into the current frame, from the
-    per-sample ``T_global`` / ``T_global_inv`` numpy matrices of the data pipeline."""
+    """(bs, 4, 4) transform taking coordinates of the cached frame into the current frame.
+
+    Taken from ``metas["T_temp2cur"]`` when the data side provides it as a device tensor (no host work
+    in the step: needed for hipGraph replay); otherwise built from the per-sample ``T_global`` /
+    ``T_global_inv`` numpy matrices like the reference does (instance_bank.py:99-104)."""
+    if "T_temp2cur" in metas:
+        return metas["T_temp2cur"].to(like.dtype)
     mats = [cur["T_global_inv"] @ prev["T_global"] for prev, cur in zip(prev_metas["img_metas"], metas["img_metas"])]
     return like.new_tensor(np.stack(mats))
 
 
+class PersistentState:
+    """Temporal state kept in buffers that are allocated once and then updated IN PLACE, so a captured
+    hipGraph of the step keeps reading and writing the same addresses on every replay."""
+
+    def _keep(self, name, value):
+        buf = getattr(self, "_p_" + name, None)
+        value = value.detach()
+        if buf is None or buf.shape != value.shape or buf.dtype != value.dtype or buf.device != value.device:
+            buf = value.clone()
+            setattr(self, "_p_" + name, buf)
+        else:
+            buf.copy_(value)
+        return buf
+
+    def _kept(self, name):
+        return getattr(self, "_p_" + name, None)
+
+    def _drop_state(self, *names):
+        for n in names:
+            setattr(self, "_p_" + n, None)
+
+
 @PLUGIN_LAYERS.register_module()
-class InstanceBank(nn.Module):
+class InstanceBank(PersistentState, nn.Module):
     def __init__(self, num_anchor, embed_dims, anchor, anchor_handler=None, num_temp_instances=0,
                  default_time_interval=0.5, confidence_decay=0.6, anchor_grad=True, feat_grad=True,
                  max_time_interval=2, class_names=None, zero_velocity_classes=None):
@@ -71,13 +98,18 @@ class InstanceBank(nn.Module):
         self.confidence = self.temp_confidence = None
         self.instance_id = None
         self.prev_id = 0
+        self._drop_state("feature", "anchor", "confidence", "timestamp")
 
     # ---- per-frame protocol ---------------------------------------------------------------
     def get(self, batch_size, metas=None, dn_metas=None):
         feature = self.instance_feature[None].expand(batch_size, -1, -1).contiguous()
         anchor = self.anchor[None].expand(batch_size, -1, -1).contiguous()
-        if self.cached_anchor is not None and batch_size == self.cached_anchor.shape[0]:
-            dt = (metas["timestamp"] - self.metas["timestamp"]).to(feature.dtype)
+        if self._kept("anchor") is not None and batch_size == self._kept("anchor").shape[0]:
+            # frame-local views of the persistent state (the warped anchors are a new tensor)
+            # clones: the persistent buffers are overwritten in cache() before backward runs
+            self.cached_feature, self.cached_anchor = self._kept("feature").clone(), self._kept("anchor").clone()
+            self.confidence = self._kept("confidence").clone()
+            dt = (metas["timestamp"] - self._kept("timestamp")).to(feature.dtype)
             self.mask = dt.abs() <= self.max_time_interval
             if self.anchor_handler is not None:
                 T = ego_motion_between(self.metas, metas, self.cached_anchor)
@@ -87,7 +119,7 @@ class InstanceBank(nn.Module):
                     moved = self.anchor_handler.anchor_projection(dn_metas["dn_anchor"].flatten(1, 2), [T],
                                                                   time_intervals=[-dt])[0]
                     dn_metas["dn_anchor"] = moved.reshape(batch_size, groups, per, -1)
-            dt = torch.where((dt != 0) & self.mask, dt, dt.new_tensor(self.default_time_interval))
+            dt = torch.where((dt != 0) & self.mask, dt, torch.full_like(dt, self.default_time_interval))
         else:
             self.reset()
             dt = feature.new_full((batch_size,), self.default_time_interval)
@@ -109,9 +141,9 @@ class InstanceBank(nn.Module):
         usable = self.mask[:, None, None]
         instance_feature = torch.where(usable, merged_feature, instance_feature)
         anchor = torch.where(usable, merged_anchor, anchor)
-        self.confidence = torch.where(self.mask[:, None], self.confidence, self.confidence.new_tensor(0))
+        self.confidence = torch.where(self.mask[:, None], self.confidence, torch.zeros_like(self.confidence))
         if self.instance_id is not None:
-            self.instance_id = torch.where(self.mask[:, None], self.instance_id, self.instance_id.new_tensor(-1))
+            self.instance_id = torch.where(self.mask[:, None], self.instance_id, torch.full_like(self.instance_id, -1))
         if tail is not None:
             instance_feature = torch.cat([instance_feature, tail[0]], dim=1)
             anchor = torch.cat([anchor, tail[1]], dim=1)
@@ -128,16 +160,20 @@ class InstanceBank(nn.Module):
             n = self.num_temp_instances
             score = torch.cat([torch.maximum(self.confidence * self.confidence_decay, score[:, :n]), score[:, n:]], dim=1)
         self.temp_confidence = score
-        self.confidence, (self.cached_feature, self.cached_anchor) = select_topk(
-            score, self.num_temp_instances, instance_feature, anchor)
+        conf, (kept_feature, kept_anchor) = select_topk(score, self.num_temp_instances, instance_feature, anchor)
         if self.class_names and self.zero_velocity_classes is not None:
             _, (kept_label,) = select_topk(score, self.num_temp_instances, label[..., None])
             kept_label = kept_label[..., 0]
             static = torch.zeros_like(kept_label, dtype=torch.bool)
             for name in self.zero_velocity_classes:
                 static |= kept_label == self.class_names.index(name)
-            self.cached_anchor[..., VX:] = torch.where(static[..., None], torch.zeros_like(self.cached_anchor[..., VX:]),
-                                                       self.cached_anchor[..., VX:])
+            kept_anchor = torch.cat([kept_anchor[..., :VX],
+                                     torch.where(static[..., None], torch.zeros_like(kept_anchor[..., VX:]),
+                                                 kept_anchor[..., VX:])], dim=-1)
+        self.confidence = self._keep("confidence", conf)
+        self.cached_feature = self._keep("feature", kept_feature)
+        self.cached_anchor = self._keep("anchor", kept_anchor)
+        self._keep("timestamp", metas["timestamp"])
 
     # ---- track ids (inference bookkeeping) -------------------------------------------------
     def get_instance_id(self, confidence, anchor=None, threshold=None):

@@ -101,6 +101,10 @@ class SparsePoint3DKeyPointsGenerator(BaseModule):
             self.learnable_fc = Linear(embed_dims, self.num_pts * 2)
         self.fix_height = np.array(fix_height)
         self.ground_height = ground_height
+        # z of every height copy, float32(ground) + float32(offset) like the reference's tensor sum;
+        # a non-persistent buffer (not in state_dict) so the forward does no host->device copy
+        z = torch.full((len(fix_height),), float(ground_height)) + torch.tensor(self.fix_height, dtype=torch.float32)
+        self.register_buffer("_height_levels", z, persistent=False)
 
     def init_weight(self):
         if self.num_learnable_pts > 0:
@@ -121,10 +125,7 @@ class SparsePoint3DKeyPointsGenerator(BaseModule):
             src = instance_feature
         offset = self.learnable_fc(src).reshape(bs, num_anchor, S, Hn, K, 2)
         xy = anchor.reshape(bs, num_anchor, S, 1, 1, -1) + offset
-        # (float32(ground) + float32(fix)) in the reference; adding the two python floats first can
-        # differ in the last bit, so do the sum in the tensor dtype
-        heights = xy.new_full((1,), float(self.ground_height)).reshape(1, 1, 1, 1, 1, 1) + \
-            xy.new_tensor(self.fix_height).reshape(1, 1, 1, Hn, 1, 1)
+        heights = self._height_levels.to(xy.dtype).reshape(1, 1, 1, Hn, 1, 1)
         z = heights.expand(bs, num_anchor, S, Hn, K, 1)
         key_points = torch.cat([xy, z], dim=-1).flatten(2, 4)
         if cur_timestamp is None or temp_timestamps is None or T_cur2temp_list is None or len(temp_timestamps) == 0:

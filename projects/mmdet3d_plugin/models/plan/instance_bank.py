@@ -13,7 +13,7 @@ from hipad_amd.compat import PLUGIN_LAYERS, Linear
 from projects.mmdet3d_plugin.ops import feature_maps_format
 
 from ..blocks import linear_relu_ln
-from ..instance_bank import select_topk
+from ..instance_bank import PersistentState, select_topk
 
 __all__ = ["PlanningInstanceBank", "front_view_encoder"]
 
@@ -28,7 +28,7 @@ def front_view_encoder(embed_dims, feature_map_scale):
 
 
 @PLUGIN_LAYERS.register_module()
-class PlanningInstanceBank(nn.Module):
+class PlanningInstanceBank(PersistentState, nn.Module):
     def __init__(self, embed_dims, anchor_paths, anchor_types=None, anchor_scales=None, num_temp_mode=0,
                  num_temp_instances=0, confidence_decay=0.6, feature_map_scale=None, max_time_interval=2,
                  feat_grad=True, anchor_grad=True, ego_fut_ts=6, ego_fut_cmd=3, ego_fut_mode=6,
@@ -72,6 +72,7 @@ class PlanningInstanceBank(nn.Module):
     def reset(self):
         self.cached_feature = self.cached_anchor = None
         self.confidence = self.metas = self.mask = None
+        self._drop_state("feature", "anchor", "confidence", "timestamp")
 
     def prepare_planning(self, batch_size, feature_maps, metas=None):
         if self.with_instance_feat:
@@ -91,9 +92,12 @@ class PlanningInstanceBank(nn.Module):
 
     def get(self, batch_size, metas, feature_maps, dn_metas=None):
         feature, anchor = self.prepare_planning(batch_size, feature_maps, metas)
-        if self.cached_anchor is None:
+        if self._kept("anchor") is None:
             return feature, anchor, None, None
-        dt = (metas["timestamp"] - self.metas["timestamp"]).to(feature.dtype)
+        # clones: the persistent buffers are overwritten in cache() before backward runs
+        self.cached_feature, self.cached_anchor = self._kept("feature").clone(), self._kept("anchor").clone()
+        self.confidence = self._kept("confidence").clone()
+        dt = (metas["timestamp"] - self._kept("timestamp")).to(feature.dtype)
         self.mask = dt.abs() <= self.max_time_interval
         bs = anchor.shape[0]
         return (feature, anchor, self.cached_feature.reshape(bs, -1, self.embed_dims),
@@ -123,7 +127,7 @@ class PlanningInstanceBank(nn.Module):
         usable = self.mask[:, None, None]
         instance_feature = torch.where(usable, merged_f, instance_feature)
         anchor = torch.where(usable, merged_a, anchor)
-        self.confidence = torch.where(usable, self.confidence, self.confidence.new_tensor(0))
+        self.confidence = torch.where(usable, self.confidence, torch.zeros_like(self.confidence))
         if tail is not None:
             instance_feature = torch.cat([instance_feature, tail[0]], dim=1)
             anchor = torch.cat([anchor, tail[1]], dim=1)
@@ -137,11 +141,12 @@ class PlanningInstanceBank(nn.Module):
         f, a, c = self._per_command(bs, instance_feature.detach(), anchor.detach(), confidence.detach().reshape(bs, -1, 1))
         self.metas = metas
         score = c.squeeze(-1).sigmoid()
-        if self.confidence is not None:
+        if self._kept("confidence") is not None:
             n = self.num_temp_mode
-            old = self.confidence.reshape(bs * groups, -1) * self.confidence_decay
+            old = self._kept("confidence").reshape(bs * groups, -1) * self.confidence_decay
             score = torch.cat([torch.maximum(old, score[:, :n]), score[:, n:]], dim=1)
         conf, (kept_f, kept_a) = select_topk(score, self.num_temp_mode, f, a)
-        self.confidence = conf.view(bs, groups, self.num_temp_mode)
-        self.cached_feature = kept_f.view(bs, groups, self.num_temp_mode, self.embed_dims)
-        self.cached_anchor = kept_a.view(bs, groups, self.num_temp_mode, self.ego_fut_ts * 2)
+        self.confidence = self._keep("confidence", conf.view(bs, groups, self.num_temp_mode))
+        self.cached_feature = self._keep("feature", kept_f.view(bs, groups, self.num_temp_mode, self.embed_dims))
+        self.cached_anchor = self._keep("anchor", kept_a.view(bs, groups, self.num_temp_mode, self.ego_fut_ts * 2))
+        self._keep("timestamp", metas["timestamp"])

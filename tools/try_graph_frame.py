@@ -1,0 +1,20 @@
+"""Whole training step replayed from hipGraphs: timing + loss trace (GPU box)."""
+import os, sys, time, warnings
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+warnings.filterwarnings("ignore")
+import torch
+from hipad_amd.frame import build_detector, SyntheticFrames, GraphedTrainStep
+plan = int(sys.argv[1]) if len(sys.argv) > 1 else 480
+bs = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+model, cfg = build_detector(stage=2, plan_queries=plan)
+model.train()
+frames = SyntheticFrames(bs=bs)
+t = time.perf_counter()
+step = GraphedTrainStep(model, cfg, frames)
+torch.cuda.synchronize()
+print("capture done in %.1f s" % (time.perf_counter() - t), flush=True)
+for i in range(12):
+    torch.cuda.synchronize(); t = time.perf_counter()
+    loss = step()
+    torch.cuda.synchronize()
+    print(i, f"loss {float(loss):.4f}  {1e3*(time.perf_counter()-t):.2f} ms  mem {torch.cuda.max_memory_allocated()/2**30:.2f} GiB", flush=True)
