@@ -118,3 +118,63 @@ def attention(q, k, v, heads, scale=None, p_drop=0.0, seed=0):
     if scale is None:
         scale = (q.shape[-1] // heads) ** -0.5
     return _Attention.apply(q, k, v, heads, float(scale), float(p_drop), int(seed))
+
+
+class _Linear(Function):
+    """y = relu?(x W[r0:r1]^T + b[r0:r1]); weight / bias gradients are accumulated IN PLACE into
+    ``weight.grad`` / ``bias.grad`` when those exist (the flat gradient buffer of hipad_amd.dist), so
+    the autograd engine has nothing to accumulate for them."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu, r0, r1):
+        shape = x.shape
+        x2 = _c32(x.reshape(-1, shape[-1]))
+        w = weight.detach()
+        if w.dtype != torch.float32 or not w.is_contiguous():
+            raise _lib.HipadError("linear: weight must be a contiguous fp32 tensor")
+        wv = w if (r0 == 0 and r1 == w.shape[0]) else w[r0:r1]
+        bv = None if bias is None else bias.detach()[r0:r1]
+        y = _lib.linear_forward(x2, wv, bv, relu)
+        ctx.save_for_backward(x2, y if relu else None)
+        ctx.weight, ctx.bias, ctx.rows, ctx.in_shape = weight, bias, (r0, r1), shape
+        ctx.mark_non_differentiable()
+        return y.view(*shape[:-1], r1 - r0)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2, y_relu = ctx.saved_tensors
+        weight, bias, (r0, r1) = ctx.weight, ctx.bias, ctx.rows
+        dy2 = _c32(dy.reshape(-1, r1 - r0))
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_b = bias is not None and ctx.needs_input_grad[2]
+        dx = torch.empty_like(x2) if need_x else None
+        ret_w = ret_b = None
+        dw = db = None
+        if need_w:
+            g = weight.grad
+            if g is not None and g.is_contiguous() and g.dtype == torch.float32:
+                dw = g[r0:r1]
+            else:
+                ret_w = torch.zeros_like(weight)
+                dw = ret_w[r0:r1]
+        if need_b:
+            g = bias.grad
+            if g is not None and g.is_contiguous() and g.dtype == torch.float32:
+                db = g[r0:r1]
+            else:
+                ret_b = torch.zeros_like(bias)
+                db = ret_b[r0:r1]
+        if need_b and not need_w:
+            raise _lib.HipadError("linear: bias gradient without weight gradient is not supported")
+        wv = weight.detach()[r0:r1]
+        _lib.linear_backward(dy2, y_relu, x2, wv, dx, dw, db)
+        return (dx.view(ctx.in_shape) if dx is not None else None), ret_w, ret_b, None, None, None
+
+
+def linear(x, weight, bias=None, relu=False, rows=None):
+    """Linear layer on the MFMA kernel (see include/hipad.h).  ``rows=(r0, r1)`` applies only those
+    output rows of ``weight`` / ``bias`` (packed projections) while gradients still land in the full
+    parameter's gradient buffer."""
+    r0, r1 = (0, weight.shape[0]) if rows is None else rows
+    return _Linear.apply(x, weight, bias, bool(relu), int(r0), int(r1))

@@ -27,6 +27,8 @@ SIGNATURES = {
     "hipad_project_points_backward": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "hipad_weights_softmax_forward": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
     "hipad_weights_softmax_backward": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p]),
+    "hipad_linear_forward": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
+    "hipad_linear_backward": (c_int, [c_void_p] * 7 + [c_int] * 3 + [c_void_p]),
     "hipad_attention_forward": (c_int, [c_void_p] * 5 + [c_int] * 5 + [ctypes.c_float, ctypes.c_float, ctypes.c_uint,
                                                                      c_void_p, c_void_p]),
     "hipad_attention_backward": (c_int, [c_void_p] * 10 + [c_int] * 5 + [ctypes.c_float, ctypes.c_float,
@@ -272,3 +274,27 @@ def attention_backward(dout, out, lse, q, k, v, heads, scale, p_drop=0.0, seed=0
                                           int(seed) & 0xFFFFFFFF, _ptr(seed_dev), stream_ptr(q.device))
     check(st, "hipad_attention_backward")
     return dq, dk, dv
+
+
+def linear_forward(x2, weight, bias, relu):
+    """x2 (M,K) fp32 contiguous, weight (N,K) (rows contiguous), bias (N,) or None -> y (M,N)."""
+    lib = load()
+    M, K = x2.shape
+    N = weight.shape[0]
+    y = torch.empty(M, N, dtype=torch.float32, device=x2.device)
+    with torch.cuda.device(x2.device):
+        st = lib.hipad_linear_forward(y.data_ptr(), x2.data_ptr(), weight.data_ptr(), _ptr(bias), M, N, K, int(relu),
+                                      stream_ptr(x2.device))
+    check(st, "hipad_linear_forward")
+    return y
+
+
+def linear_backward(dy2, y_relu, x2, weight, dx, dw, db):
+    """dx overwritten (or None); dw / db accumulated into (or None)."""
+    lib = load()
+    M, K = x2.shape
+    N = weight.shape[0]
+    with torch.cuda.device(x2.device):
+        st = lib.hipad_linear_backward(_ptr(dx), _ptr(dw), _ptr(db), dy2.data_ptr(), _ptr(y_relu), x2.data_ptr(),
+                                       weight.data_ptr(), M, N, K, stream_ptr(x2.device))
+    check(st, "hipad_linear_backward")

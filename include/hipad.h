@@ -182,6 +182,25 @@ int hipad_attention_backward(float *dq, float *dk, float *dv, float *delta_ws, c
                              float softmax_scale, float p_drop, unsigned seed, const unsigned *seed_dev,
                             hipad_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Linear layer on the matrix cores.
+ * Replaces: the torch / mmcv ``Linear`` calls of the decoder blocks (reference
+ *           models/blocks.py:32-42, 104-118, 367-396; models/attention.py:27-34, 127-143; the
+ *           refinement heads and anchor encoders), i.e. cuBLAS GEMM + bias + ReLU + autograd
+ *           accumulate kernels.
+ *   forward : y[M,N] = relu?(x[M,K] weight[N,K]^T + bias[N])        (bias may be NULL)
+ *   backward: dx[M,K] = g weight ;  dw[N,K] += g^T x ;  db[N] += colsum(g)
+ *             with g = dy where y_relu > 0 (y_relu = the forward output of a ReLU layer, or NULL
+ *             for no activation).  dx is overwritten; dw / db are ACCUMULATED with fp32 atomics
+ *             (pass the parameter's gradient buffer: no separate accumulation pass); any of
+ *             dx / (dw, db) may be NULL.
+ * fp32 in memory, operands rounded to bf16 on load, fp32 accumulation (v_mfma_f32_16x16x32_bf16).
+ * ---------------------------------------------------------------------------------- */
+int hipad_linear_forward(float *y, const float *x, const float *weight, const float *bias, int M, int N,
+                         int K, int relu, hipad_stream_t stream);
+int hipad_linear_backward(float *dx, float *dw, float *db, const float *dy, const float *y_relu,
+                          const float *x, const float *weight, int M, int N, int K, hipad_stream_t stream);
+
 /* Tuning knob (host side, process-wide): target number of (point, camera) pairs one
  * wavefront owns in the forward / backward kernels.  <=0 restores the default. */
 void hipad_daf_set_pairs_per_wave(int fwd, int bwd);
