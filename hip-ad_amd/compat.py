@@ -133,7 +133,34 @@ else:
     from mmdet.models import BACKBONES, NECKS  # type: ignore  # noqa: F401
 
 
-Linear = nn.Linear
+class Linear(nn.Linear):
+    """nn.Linear (same parameters / state_dict) that runs on the hand-written MFMA kernel for CUDA
+    inputs when ``hipad_amd.functional.LINEAR_MODE == "mfma_bf16"`` (bias and an optional ReLU fused in
+    the epilogue, weight/bias gradients accumulated in place), and on torch's fp32 GEMM otherwise."""
+
+    fuse_relu = False
+
+    def forward(self, x):
+        from . import functional as HF
+        if x.is_cuda and HF.LINEAR_MODE == "mfma_bf16":
+            return HF.linear(x, self.weight, self.bias, relu=self.fuse_relu)
+        y = nn.functional.linear(x, self.weight, self.bias)
+        return nn.functional.relu(y) if self.fuse_relu else y
+
+
+def linear_relu(in_features, out_features):
+    """(Linear with the ReLU fused into its epilogue, placeholder) -- two modules, so Sequential
+    indices (and therefore state_dict keys) match a plain [Linear, ReLU] pair."""
+    lin = Linear(in_features, out_features)
+    lin.fuse_relu = True
+    return lin, FusedReLU()
+
+
+class FusedReLU(nn.Module):
+    """Occupies the ReLU slot after a Linear whose kernel already applied the ReLU."""
+
+    def forward(self, x):
+        return x
 
 
 class Scale(nn.Module):

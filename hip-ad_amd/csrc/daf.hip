@@ -32,6 +32,21 @@
 
 namespace hipad {
 
+__global__ __launch_bounds__(256) void fill_zero_kernel(uint32_t *__restrict__ p, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0u;
+}
+
+int fill_zero(void *ptr, size_t bytes, hipStream_t stream) {
+  if (!ptr || bytes == 0) return HIPAD_OK;
+  if (bytes & 3) return HIPAD_EINVAL;
+  const size_t n = bytes >> 2;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(fill_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (uint32_t *)ptr, n);
+  return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
+}
+
 // =====================================================================================
 // Forward, fast path: C == 256, (C/G) % 4 == 0.
 // grid = ceil(n_items / 4) blocks of 256 threads; one wave per item.
@@ -626,10 +641,8 @@ int hipad_daf_backward(const float *feat, const int32_t *spatial_shape,
     if (overwrite) {
       // generic path accumulates with atomics: clear what the flag promises to overwrite
       const size_t npair = (size_t)bs * A * P * cams;
-      if (grad_loc && hipMemsetAsync(grad_loc, 0, npair * 2 * sizeof(float), stream) != hipSuccess)
-        return HIPAD_ELAUNCH;
-      if (grad_w && hipMemsetAsync(grad_w, 0, npair * L * G * sizeof(float), stream) != hipSuccess)
-        return HIPAD_ELAUNCH;
+      if (grad_loc && fill_zero(grad_loc, npair * 2 * sizeof(float), stream) != HIPAD_OK) return HIPAD_ELAUNCH;
+      if (grad_w && fill_zero(grad_w, npair * L * G * sizeof(float), stream) != HIPAD_OK) return HIPAD_ELAUNCH;
     }
     const int cblocks = (C + kWave - 1) / kWave;
     const long nw = (long)n_items * cblocks;

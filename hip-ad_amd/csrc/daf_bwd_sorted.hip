@@ -48,7 +48,7 @@ namespace hipad {
 // level first while every camera's map of that level still fits the table.
 // ------------------------------------------------------------------------------------------
 constexpr int kTapBlock = 1024;
-constexpr int kLdsRows = 24576;  // 96 KiB of counters
+constexpr int kLdsRows = 14336;  // 56 KiB of counters (static LDS kept under 64 KiB: see DESIGN.md, graph replay)
 constexpr int kMaxMaps = 64;     // cams * L handled by the LDS path
 
 template <bool PLACE>
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void daf_bwd_feat_kernel(
     const int *__restrict__ ends /* cursor after placement */, const int *__restrict__ total_p,
     const float *__restrict__ gout,
     const float *__restrict__ loc, const float *__restrict__ wts, const int *__restrict__ ss,
-    const int *__restrict__ start, int R, int cams, int num_feat, int L, int A, int P) {
+    const int *__restrict__ start, int R, int cams, int num_feat, int L, int A, int P, int npairL) {
   __shared__ float wc_s[4][kWave][8];
   const int lane = threadIdx.x & (kWave - 1);
   const int wv = threadIdx.x >> 6;
@@ -225,8 +225,11 @@ __global__ __launch_bounds__(256) void daf_bwd_feat_kernel(
     float wq[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) wq[k] = 0.f;
-    if (lane < n) {
-      const int id = taps[t0 + lane];
+    const int tap_id = lane < n ? taps[t0 + lane] : -1;
+    // a slot that is not a tap of THIS call (never expected: count and place walk the same pairs)
+    // must not be used as an index: it is skipped instead of trusted
+    if (lane < n && tap_id >= 0 && (tap_id >> 2) < npairL) {
+      const int id = tap_id;
       const int corner = id & 3;
       const int q = id >> 2;
       const int pair = q / L, s = q - pair * L;
@@ -253,41 +256,37 @@ __global__ __launch_bounds__(256) void daf_bwd_feat_kernel(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    // ---- walk the batch
+    // ---- walk the batch (row < 0 marks a skipped slot: contributes nothing, is never flushed)
+    auto flush = [&](int r, int ex, const float4 &o, const float4 &a4) {
+      if (r < 0) return;
+      float4 *p = gfeat4 + (size_t)r * 64 + lane;
+      if (ex) {
+        *p = make_float4(o.x + a4.x, o.y + a4.y, o.z + a4.z, o.w + a4.w);
+      } else {
+        float *pf = reinterpret_cast<float *>(p);
+        atomicAdd(pf + 0, a4.x); atomicAdd(pf + 1, a4.y); atomicAdd(pf + 2, a4.z); atomicAdd(pf + 3, a4.w);
+      }
+    };
     int cur = rl_i(row, 0);
     int cur_excl = rl_i(excl, 0);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 old = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (cur_excl) old = gfeat4[(size_t)cur * 64 + lane];
+    if (cur >= 0 && cur_excl) old = gfeat4[(size_t)cur * 64 + lane];
     for (int t = 0; t < n; ++t) {
       const int rt = rl_i(row, t);
       const int at = rl_i(anchor, t);
       const float4 g4 = gout4[(size_t)at * 64 + lane];
       const float wc = wc_s[wv][t][g];
       if (rt != cur) {
-        float4 *p = gfeat4 + (size_t)cur * 64 + lane;
-        if (cur_excl) {
-          *p = make_float4(old.x + acc.x, old.y + acc.y, old.z + acc.z, old.w + acc.w);
-        } else {
-          float *pf = reinterpret_cast<float *>(p);
-          atomicAdd(pf + 0, acc.x); atomicAdd(pf + 1, acc.y); atomicAdd(pf + 2, acc.z); atomicAdd(pf + 3, acc.w);
-        }
+        flush(cur, cur_excl, old, acc);
         cur = rt;
         cur_excl = rl_i(excl, t);
         acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (cur_excl) old = gfeat4[(size_t)cur * 64 + lane];
+        if (cur >= 0 && cur_excl) old = gfeat4[(size_t)cur * 64 + lane];
       }
       acc.x += wc * g4.x; acc.y += wc * g4.y; acc.z += wc * g4.z; acc.w += wc * g4.w;
     }
-    {
-      float4 *p = gfeat4 + (size_t)cur * 64 + lane;
-      if (cur_excl) {
-        *p = make_float4(old.x + acc.x, old.y + acc.y, old.z + acc.z, old.w + acc.w);
-      } else {
-        float *pf = reinterpret_cast<float *>(p);
-        atomicAdd(pf + 0, acc.x); atomicAdd(pf + 1, acc.y); atomicAdd(pf + 2, acc.z); atomicAdd(pf + 3, acc.w);
-      }
-    }
+    flush(cur, cur_excl, old, acc);
     __builtin_amdgcn_wave_barrier();  // wc_s[wv] is rewritten by the next batch
   }
 }
@@ -468,7 +467,7 @@ int daf_bwd_sorted_feat(const float *, const int *ss, const int *start, const fl
   if (!workspace || workspace_bytes < w.bytes) return HIPAD_EWORKSPACE;
   const int R = d.bs * d.num_feat;
   const int npair = d.bs * d.A * d.P * d.cams;
-  if (hipMemsetAsync(w.cnt, 0, (size_t)(R + 1) * 4, stream) != hipSuccess) return HIPAD_ELAUNCH;
+  if (fill_zero(w.cnt, (size_t)(R + 1) * 4, stream) != HIPAD_OK) return HIPAD_ELAUNCH;
   const dim3 pg((npair + kTapBlock - 1) / kTapBlock), pb(kTapBlock);
   hipLaunchKernelGGL(daf_tap_pass_kernel<false>, pg, pb, 0, stream, w.cnt, (int *)nullptr, ss, start, loc,
                      npair, d.cams, d.num_feat, d.L, d.P * d.cams * d.A);
@@ -482,7 +481,7 @@ int daf_bwd_sorted_feat(const float *, const int *ss, const int *start, const fl
   if (nb > 2048) nb = 2048;
   hipLaunchKernelGGL(daf_bwd_feat_kernel, dim3((unsigned)nb), dim3(256), 0, stream, gfeat, (const int *)w.taps,
                      (const int *)w.offs, (const int *)w.cursor, (const int *)(w.cnt + R), gout, loc, wts, ss, start, R, d.cams, d.num_feat,
-                     d.L, d.A, d.P);
+                     d.L, d.A, d.P, npair * d.L);
   return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
 }
 

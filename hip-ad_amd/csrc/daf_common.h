@@ -91,6 +91,12 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v + __shfl_xor(v, 32);
 }
 
+// Zero fill as a kernel: the library never uses hipMemsetAsync -- inside a captured hipGraph every node
+// is then a kernel node in one dependency chain (memset nodes were the one graph-node type only this
+// library produced; see DESIGN.md "hipGraph").
+__global__ void fill_zero_kernel(uint32_t *__restrict__ p, size_t n);
+int fill_zero(void *ptr, size_t bytes, hipStream_t stream);
+
 // ---- sorted (atomic-free) feature-gradient path, daf_bwd_sorted.hip -------------------
 struct DafDims {
   int bs, cams, num_feat, C, L, A, P, G;

@@ -23,6 +23,7 @@
 #include <stdint.h>
 
 #include "hipad.h"
+#include "daf_common.h"
 
 namespace hipad {
 
@@ -278,8 +279,7 @@ int hipad_weights_softmax_backward(float *grad_u, float *grad_v, const float *gr
                                    hipad_stream_t stream) {
   if (!grad_u || !grad_weights || !stats || !u || (v && !grad_v)) return HIPAD_EINVAL;
   if (bs <= 0 || A <= 0 || cams <= 0 || L <= 0 || P <= 0 || G <= 0 || 256 % G) return HIPAD_EINVAL;
-  if (grad_v &&
-      hipMemsetAsync(grad_v, 0, (size_t)bs * cams * L * P * G * sizeof(float), (hipStream_t)stream) != hipSuccess)
+  if (grad_v && fill_zero(grad_v, (size_t)bs * cams * L * P * G * sizeof(float), (hipStream_t)stream) != HIPAD_OK)
     return HIPAD_ELAUNCH;
   hipLaunchKernelGGL(weights_softmax_bwd_kernel, dim3((unsigned)(bs * A)), dim3(256), 0, (hipStream_t)stream,
                      grad_u, v ? grad_v : nullptr, grad_weights, stats, u, v, keep, A, cams, L, P, G,

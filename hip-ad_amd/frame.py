@@ -143,8 +143,11 @@ class GraphedTrainStep:
         self.img = torch.empty_like(img)
         self.ts = torch.zeros(bs, dtype=torch.float64, device=dev)
         self.T = torch.zeros(bs, 4, 4, dtype=torch.float32, device=dev)
-        self._T_host = torch.zeros(bs, 4, 4, dtype=torch.float32).pin_memory()
-        self._ts_host = torch.zeros(bs, dtype=torch.float64).pin_memory()
+        # pinned staging ring: the host may run several frames ahead of the GPU, so a staging buffer is
+        # not rewritten until RING further frames have been enqueued behind its asynchronous copy
+        self._ring = [(torch.zeros(bs, 4, 4, dtype=torch.float32).pin_memory(),
+                       torch.zeros(bs, dtype=torch.float64).pin_memory(), torch.cuda.Event()) for _ in range(8)]
+        self._ring_i = 0
         self.data = dict(projection_mat=data["projection_mat"], image_wh=data["image_wh"], timestamp=self.ts,
                          T_temp2cur=self.T, img_metas=data["img_metas"], gt_ego_fut_cmd=data["gt_ego_fut_cmd"],
                          target_point=data["target_point"])
@@ -186,11 +189,15 @@ class GraphedTrainStep:
         Ts = [m["T_global"] for m in data["img_metas"]]
         Tinv = [m["T_global_inv"] for m in data["img_metas"]]
         prev = self._prev_T if self._prev_T is not None else Ts
-        self._T_host.copy_(torch.from_numpy(np.stack([ti @ tp for ti, tp in zip(Tinv, prev)]).astype(np.float32)))
+        T_host, ts_host, done = self._ring[self._ring_i]
+        self._ring_i = (self._ring_i + 1) % len(self._ring)
+        done.synchronize()  # the copy that last used this slot has finished (8 frames ago: never blocks in practice)
+        T_host.copy_(torch.from_numpy(np.stack([ti @ tp for ti, tp in zip(Tinv, prev)]).astype(np.float32)))
         self._prev_T = Ts
-        self._ts_host.copy_(data["timestamp"].cpu() if data["timestamp"].is_cuda is False else self._ts_from(data))
-        self.T.copy_(self._T_host, non_blocking=True)
-        self.ts.copy_(self._ts_host, non_blocking=True)
+        ts_host.copy_(self._ts_from(data))
+        self.T.copy_(T_host, non_blocking=True)
+        self.ts.copy_(ts_host, non_blocking=True)
+        done.record()
         if self.model.use_grid_mask and getattr(self.model.grid_mask, "_last_h", None) is not None:
             self.model.grid_mask.randomize(self.img.device)
 
@@ -223,7 +230,7 @@ class GraphedTrainStep:
         return self.loss
 
 
-DECODER_DTYPE = torch.bfloat16  # GEMMs of the decoder under autocast (norms / softmax / kernels stay fp32)
+DECODER_DTYPE = torch.float32  # no autocast in the decoder: its Linear layers are the bf16-operand MFMA kernel
 
 
 def _frame_loss(det, img, data):

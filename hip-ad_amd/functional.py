@@ -120,6 +120,30 @@ def attention(q, k, v, heads, scale=None, p_drop=0.0, seed=0):
     return _Attention.apply(q, k, v, heads, float(scale), float(p_drop), int(seed))
 
 
+import os as _os
+
+LINEAR_MODE = _os.environ.get("HIPAD_LINEAR_MODE", "mfma_bf16")  # "torch_fp32": library fp32 GEMMs (fp32 parity runs)
+LINEAR_INPLACE_GRAD = _os.environ.get("HIPAD_LINEAR_INPLACE_GRAD", "1") == "1"
+LINEAR_BWD = _os.environ.get("HIPAD_LINEAR_BWD", "mfma")  # "torch": debugging aid, backward by library matmuls
+
+
+class linear_mode:
+    """Context manager: with linear_mode("torch_fp32"): ..."""
+
+    def __init__(self, mode):
+        if mode not in ("mfma_bf16", "torch_fp32"):
+            raise ValueError(mode)
+        self.mode = mode
+
+    def __enter__(self):
+        global LINEAR_MODE
+        self.prev, LINEAR_MODE = LINEAR_MODE, self.mode
+
+    def __exit__(self, *exc):
+        global LINEAR_MODE
+        LINEAR_MODE = self.prev
+
+
 class _Linear(Function):
     """y = relu?(x W[r0:r1]^T + b[r0:r1]); weight / bias gradients are accumulated IN PLACE into
     ``weight.grad`` / ``bias.grad`` when those exist (the flat gradient buffer of hipad_amd.dist), so
@@ -152,14 +176,14 @@ class _Linear(Function):
         ret_w = ret_b = None
         dw = db = None
         if need_w:
-            g = weight.grad
+            g = weight.grad if LINEAR_INPLACE_GRAD else None
             if g is not None and g.is_contiguous() and g.dtype == torch.float32:
                 dw = g[r0:r1]
             else:
                 ret_w = torch.zeros_like(weight)
                 dw = ret_w[r0:r1]
         if need_b:
-            g = bias.grad
+            g = bias.grad if LINEAR_INPLACE_GRAD else None
             if g is not None and g.is_contiguous() and g.dtype == torch.float32:
                 db = g[r0:r1]
             else:
@@ -168,7 +192,16 @@ class _Linear(Function):
         if need_b and not need_w:
             raise _lib.HipadError("linear: bias gradient without weight gradient is not supported")
         wv = weight.detach()[r0:r1]
-        _lib.linear_backward(dy2, y_relu, x2, wv, dx, dw, db)
+        if LINEAR_BWD == "torch":
+            g = dy2 if y_relu is None else dy2 * (y_relu > 0)
+            if dx is not None:
+                torch.matmul(g, wv, out=dx)
+            if dw is not None:
+                dw.add_(g.t() @ x2)
+            if db is not None:
+                db.add_(g.sum(0))
+        else:
+            _lib.linear_backward(dy2, y_relu, x2, wv, dx, dw, db)
         return (dx.view(ctx.in_shape) if dx is not None else None), ret_w, ret_b, None, None, None
 
 
@@ -177,4 +210,7 @@ def linear(x, weight, bias=None, relu=False, rows=None):
     output rows of ``weight`` / ``bias`` (packed projections) while gradients still land in the full
     parameter's gradient buffer."""
     r0, r1 = (0, weight.shape[0]) if rows is None else rows
+    if not (x.is_cuda and LINEAR_MODE == "mfma_bf16"):
+        y = torch.nn.functional.linear(x, weight[r0:r1], None if bias is None else bias[r0:r1])
+        return torch.relu(y) if relu else y
     return _Linear.apply(x, weight, bias, bool(relu), int(r0), int(r1))

@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from hipad_amd import functional as HF
-from hipad_amd.compat import ATTENTION, BaseModule, build_dropout
+from hipad_amd.compat import ATTENTION, BaseModule, Linear, build_dropout
 
 __all__ = ["MultiheadFlashAttention", "FlashMHA", "gen_sineembed_for_position"]
 
@@ -42,7 +42,7 @@ class FlashMHA(nn.Module):
         self.in_proj_bias = nn.Parameter(torch.empty(3 * embed_dim)) if bias else None
         if not bias:
             self.register_parameter("in_proj_bias", None)
-        self.out_proj = nn.Linear(embed_dim, embed_dim, bias=bias)
+        self.out_proj = Linear(embed_dim, embed_dim, bias=bias)
         self._reset_parameters()
 
     def _reset_parameters(self):
@@ -55,12 +55,12 @@ class FlashMHA(nn.Module):
         E = self.embed_dim
         W, b = self.in_proj_weight, self.in_proj_bias
         if q is k and k is v:
-            return F.linear(q, W, b).split(E, dim=-1)
-        bq, bk, bv = (None, None, None) if b is None else b.split(E)
+            return HF.linear(q, W, b).split(E, dim=-1)
         if q is k:
-            qk = F.linear(q, W[: 2 * E], None if b is None else b[: 2 * E])
-            return qk[..., :E], qk[..., E:], F.linear(v, W[2 * E:], bv)
-        return F.linear(q, W[:E], bq), F.linear(k, W[E: 2 * E], bk), F.linear(v, W[2 * E:], bv)
+            qk = HF.linear(q, W, b, rows=(0, 2 * E))
+            return qk[..., :E], qk[..., E:], HF.linear(v, W, b, rows=(2 * E, 3 * E))
+        return (HF.linear(q, W, b, rows=(0, E)), HF.linear(k, W, b, rows=(E, 2 * E)),
+                HF.linear(v, W, b, rows=(2 * E, 3 * E)))
 
     def forward(self, q, k, v, key_padding_mask=None):
         if key_padding_mask is not None:

@@ -20,7 +20,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from hipad_amd import functional as HF
-from hipad_amd.compat import (ATTENTION, FEEDFORWARD_NETWORK, PLUGIN_LAYERS, BaseModule, Linear, Sequential,
+from hipad_amd.compat import (ATTENTION, FEEDFORWARD_NETWORK, PLUGIN_LAYERS, BaseModule, FusedReLU, Linear, Sequential,
+                              linear_relu,
                               build_activation_layer, build_dropout, build_from_cfg, build_norm_layer,
                               constant_init, xavier_init)
 
@@ -35,7 +36,7 @@ def linear_relu_ln(embed_dims, in_loops, out_loops, input_dims=None):
     stack = []
     for _ in range(out_loops):
         for _ in range(in_loops):
-            stack += [Linear(width_in, embed_dims), nn.ReLU(inplace=True)]
+            stack += list(linear_relu(width_in, embed_dims))  # ReLU fused into the GEMM epilogue
             width_in = embed_dims
         stack.append(nn.LayerNorm(embed_dims))
     return stack
@@ -102,7 +103,7 @@ class DeformableFeatureAggregation(BaseModule):
             cam_in = metas["projection_mat"][:, :, :3].reshape(bs, self.num_cams, -1)
             cam_embed = self.camera_encoder(cam_in.to(feature.dtype))
             u = self.weights_fc(feature)                       # (bs, A, n): anchor part + bias
-            v = F.linear(cam_embed, self.weights_fc.weight)    # (bs, cams, n): camera part
+            v = HF.linear(cam_embed, self.weights_fc.weight)   # (bs, cams, n): camera part
             w = HF.sampling_weights(u, v, keep, L, P, G)
         else:
             u = self.weights_fc(feature).reshape(bs, num_anchor, self.num_cams, L * P * G)
@@ -183,8 +184,13 @@ class AsymmetricFFN(BaseModule):
         width = embed_dims if in_channels is None else in_channels
         self.pre_norm = build_norm_layer(pre_norm, width)[1] if pre_norm is not None else None
         stages = []
+        relu_act = isinstance(self.activate, nn.ReLU)
         for _ in range(num_fcs - 1):
-            stages.append(Sequential(Linear(width, feedforward_channels), self.activate, nn.Dropout(ffn_drop)))
+            if relu_act:
+                first, act = linear_relu(width, feedforward_channels)
+            else:
+                first, act = Linear(width, feedforward_channels), self.activate
+            stages.append(Sequential(first, act, nn.Dropout(ffn_drop)))
             width = feedforward_channels
         stages += [Linear(feedforward_channels, embed_dims), nn.Dropout(ffn_drop)]
         self.layers = Sequential(*stages)

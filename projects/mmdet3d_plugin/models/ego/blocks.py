@@ -1,7 +1,7 @@
 """Ego-status heads (registered names / keywords / parameter names of the reference's models/ego/blocks.py)."""
 import torch.nn as nn
 
-from hipad_amd.compat import PLUGIN_LAYERS, BaseModule, Linear, bias_init_with_prob
+from hipad_amd.compat import PLUGIN_LAYERS, BaseModule, Linear, bias_init_with_prob, linear_relu
 
 from ..blocks import linear_relu_ln
 
@@ -9,8 +9,8 @@ __all__ = ["SparseEgoRefinementModule", "EgoStatusRefinementModule"]
 
 
 def _mlp3(embed_dims, out_dim):
-    return nn.Sequential(nn.Linear(embed_dims, embed_dims), nn.ReLU(), nn.Linear(embed_dims, embed_dims), nn.ReLU(),
-                         nn.Linear(embed_dims, out_dim))
+    return nn.Sequential(*linear_relu(embed_dims, embed_dims), *linear_relu(embed_dims, embed_dims),
+                         Linear(embed_dims, out_dim))
 
 
 @PLUGIN_LAYERS.register_module()

@@ -38,12 +38,23 @@ class GridMask(nn.Module):
         ln = min(max(int(d * self.ratio + 0.5), 1), d - 1)
         st_h, st_w = np.random.randint(d), np.random.randint(d)
         np.random.randint(self.rotate)  # keeps the host RNG stream aligned with the reference
-        if getattr(self, "_host", None) is None:
-            self._host = torch.empty(5, dtype=torch.float32).pin_memory() if torch.cuda.is_available() else torch.empty(5)
-        self._host.copy_(torch.tensor([apply, d, ln, st_h, st_w], dtype=torch.float32))
         if getattr(self, "_dev", None) is None or self._dev.device != torch.device(device):
             self._dev = torch.empty(5, dtype=torch.float32, device=device)
-        self._dev.copy_(self._host, non_blocking=True)
+        on_gpu = torch.device(device).type == "cuda"
+        if getattr(self, "_ring", None) is None:
+            # staging ring: the host may be frames ahead of the GPU; a slot is rewritten only after the
+            # asynchronous copy that last read it has completed
+            self._ring = [(torch.empty(5, dtype=torch.float32).pin_memory() if on_gpu else torch.empty(5),
+                           torch.cuda.Event() if on_gpu else None) for _ in range(8)]
+            self._ring_i = 0
+        host, done = self._ring[self._ring_i]
+        self._ring_i = (self._ring_i + 1) % len(self._ring)
+        if done is not None:
+            done.synchronize()
+        host.copy_(torch.tensor([apply, d, ln, st_h, st_w], dtype=torch.float32))
+        self._dev.copy_(host, non_blocking=True)
+        if done is not None:
+            done.record()
 
     @staticmethod
     def _stripes(length, canvas, d, ln, st, device):

@@ -203,8 +203,8 @@ class SparseOneDecoder(BaseModule):
             slots.append(None if cfg is None else build_from_cfg(cfg, registry))
         self.layers = nn.ModuleList(slots)
         if decouple_attn:
-            self.fc_before = nn.Linear(embed_dims, embed_dims * 2, bias=False)
-            self.fc_after = nn.Linear(embed_dims * 2, embed_dims, bias=False)
+            self.fc_before = Linear(embed_dims, embed_dims * 2, bias=False)
+            self.fc_after = Linear(embed_dims * 2, embed_dims, bias=False)
         else:
             self.fc_before, self.fc_after = nn.Identity(), nn.Identity()
         self.run_step = 0

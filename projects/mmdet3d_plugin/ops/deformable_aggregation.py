@@ -17,6 +17,11 @@ from torch.autograd.function import Function, once_differentiable
 from hipad_amd import lib as _lib
 
 
+import os as _os
+
+_ATOMIC_FEAT = _os.environ.get("HIPAD_DAF_ATOMIC", "0") == "1"  # debugging aid: one-pass atomic scatter backward
+
+
 def _as_i32(t):
     if t.dtype == torch.int32 and t.is_contiguous():
         return t
@@ -102,5 +107,6 @@ class DeformableAggregationFunction(Function):
             grad_token = torch.zeros((), dtype=feat.dtype, device=feat.device)
         elif need_feat:
             grad_feat = ret_feat = torch.zeros_like(feat)
-        _lib.daf_backward(feat, ss, st, loc, w, grad_output, grad_feat, grad_loc, grad_w, overwrite_loc_w=True)
+        _lib.daf_backward(feat, ss, st, loc, w, grad_output, grad_feat, grad_loc, grad_w, overwrite_loc_w=True,
+                          atomic_feat=_ATOMIC_FEAT)
         return ret_feat, None, None, grad_loc, grad_w, grad_token
