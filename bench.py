@@ -34,8 +34,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
+import hipad_amd  # noqa: E402,F401  sets the HIP runtime flags graph replay needs -- before torch is imported
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 
@@ -48,6 +50,8 @@ def parse():
     ap.add_argument("--workload", default="stage2_full", choices=("stage2_full", "daf_stage2"))
     ap.add_argument("--plan-queries", type=int, default=480, choices=(48, 480))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch the step kernel by kernel instead of replaying hipGraphs")
+    ap.add_argument("--bs", type=int, default=1, help="frames per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -175,24 +179,40 @@ class DafStage2:
 class Stage2Full:
     """One training step of the whole model per frame (see module docstring)."""
 
-    def __init__(self, device, seed, plan_queries=480, bs=1):
+    def __init__(self, device, seed, plan_queries=480, bs=1, eager=False):
         import warnings
         warnings.filterwarnings("ignore", category=DeprecationWarning)
-        from hipad_amd.frame import SyntheticFrames, TrainStep, build_detector
+        from hipad_amd.frame import GraphedTrainStep, SyntheticFrames, TrainStep, build_detector
         torch.manual_seed(1234)  # identical initial weights on every rank (then broadcast anyway)
         self.model, self.cfg = build_detector(stage=2, input_hw=(256, 704), plan_queries=plan_queries, device=device)
         self.model.train()
         self.frames = SyntheticFrames(bs=bs, input_hw=(256, 704), device=device, seed=seed)
-        self.train_step = TrainStep(self.model, self.cfg)
-        self.bs, self.plan_queries = bs, plan_queries
+        self.bs, self.plan_queries, self.eager = bs, plan_queries, eager
+        if eager:
+            self.train_step = TrainStep(self.model, self.cfg)
+            self.graphed = None
+        else:
+            self.graphed = GraphedTrainStep(self.model, self.cfg, self.frames)  # warms up (cold frames) + captures
+            self.train_step = self.graphed.inner
         self.daf = DafStage2(device, seed, plan_queries)  # op-level harness for the roofline / cpu legs
 
     def step(self):
-        self.train_step(*self.frames.next())
+        if self.graphed is not None:
+            self.last_loss = self.graphed()
+        else:
+            self.last_loss = self.train_step(*self.frames.next())
+
+    def sanity(self):
+        """Loss and pre-clip gradient norm of the last step (a step that computes garbage still runs fast)."""
+        loss, gn = float(self.last_loss), float(self.train_step.grad_norm)
+        return dict(loss=round(loss, 4), grad_norm_before_clip=round(gn, 3), finite=bool(np.isfinite(loss) and np.isfinite(gn)))
 
     def breakdown(self, reps=5):
-        """ms per frame of the encoder forward, decoder forward and the rest, by HIP events."""
+        """ms per frame of the encoder forward, decoder forward and the rest, by HIP events, launched
+        EAGERLY (so it includes launch gaps the graph replay does not have; shares, not the headline)."""
         from hipad_amd.frame import DECODER_DTYPE, surrogate_objective
+        if self.model.use_grid_mask:
+            self.model.grid_mask.external_randomize = False
         ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
         acc = dict(encoder_fwd=0.0, decoder_fwd=0.0, backward_opt=0.0)
         for _ in range(reps):
@@ -202,7 +222,7 @@ class Stage2Full:
             e[0].record()
             fm, depths = self.model.extract_feat(img, True, data)
             e[1].record()
-            with torch.autocast("cuda", dtype=DECODER_DTYPE):
+            with torch.autocast("cuda", dtype=DECODER_DTYPE, enabled=DECODER_DTYPE != torch.float32):
                 outs = self.model.head(img, fm, data)
             loss = surrogate_objective(outs, depths)
             e[2].record()
@@ -237,7 +257,8 @@ def main():
     rank, world, local = dist_setup(a.gpus)
     dev = torch.device("cuda", local)
     full = a.workload == "stage2_full"
-    wl = Stage2Full(dev, seed=rank, plan_queries=a.plan_queries) if full else DafStage2(dev, seed=rank, plan_queries=a.plan_queries)
+    wl = (Stage2Full(dev, seed=rank, plan_queries=a.plan_queries, bs=a.bs, eager=a.eager) if full
+          else DafStage2(dev, seed=rank, plan_queries=a.plan_queries))
 
     def barrier():
         if world > 1:
@@ -254,6 +275,9 @@ def main():
     from hipad_amd.dist import max_over_ranks
     dt = max_over_ranks(time.perf_counter() - t0, dev)
 
+    sanity = wl.sanity() if full else None
+    if sanity is not None and not sanity["finite"]:
+        raise SystemExit(f"bench: the training step went non-finite ({sanity}); refusing to report a throughput")
     daf = wl.daf if full else wl
     roof = roofline_of(daf)
     if full:
@@ -263,8 +287,10 @@ def main():
                     "head, bf16 GEMMs / bf16-operand attention, fp32 aggregation; surrogate objective: the reference's "
                     "loss + Hungarian assignment are not built yet (SURVEY 8f row 1)")
         dtype = "bf16"
-        cfg = dict(workload=workload, frames_per_gpu_per_step=1, plan_queries=a.plan_queries, parallelism=f"dp{world}",
-                   frame_breakdown_ms=wl.breakdown() if rank == 0 else None,
+        cfg = dict(workload=workload, frames_per_gpu_per_step=a.bs, plan_queries=a.plan_queries, parallelism=f"dp{world}",
+                   launch="eager" if a.eager else "hipGraph replay (fwd+bwd graph, eager RCCL all-reduce, clip+AdamW graph)",
+                   eager_frame_breakdown_ms=wl.breakdown() if (rank == 0 and a.eager) else None,
+                   last_step=sanity,
                    roofline_scope="dominant hand-written kernel (deformable aggregation); encoder convolutions and "
                                   "GEMMs are MIOpen / hipBLASLt library calls")
     else:
@@ -275,7 +301,7 @@ def main():
         dtype = "f32"
         cfg = dict(workload=workload, frames_per_gpu_per_step=1, plan_queries=a.plan_queries, parallelism=f"dp{world}")
     out = dict(metric="frames/sec (6-cam 704x256, 900+100+6+48 queries) fwd+bwd at 1/2/4/8 GPUs",
-               value=round(world * a.steps / dt, 3), unit="frames/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
+               value=round(world * a.steps * (a.bs if full else 1) / dt, 3), unit="frames/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
                ms_per_step=round(dt / a.steps * 1e3, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
                dtype=dtype, data="synthetic", config=cfg, roofline=roof)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -101,7 +101,9 @@ class TrainStep:
         return loss
 
     def update(self):
-        torch.nn.utils.clip_grad_norm_(self.params, self.max_norm, foreach=True)
+        # total norm BEFORE clipping, kept as a device scalar (read it for sanity checks: a captured step
+        # that computes garbage gradients still "trains" once they are clipped)
+        self.grad_norm = torch.nn.utils.clip_grad_norm_(self.params, self.max_norm, foreach=True)
         self.opt.step()
 
     def __call__(self, img, data):
@@ -128,8 +130,14 @@ class GraphedTrainStep:
     left out of the captured step.
     """
 
+    debug_hook = None  # tools/diag_stale.py: called with "before_capture" / "after_capture"
+
     def __init__(self, model, cfg, frames, comm_dtype=None, warm_frames=3):
         import torch.distributed as dist
+        from . import runtime_env
+        if not runtime_env.graph_replay_is_safe():
+            raise RuntimeError("captured training steps need %s in the environment before the HIP runtime starts "
+                               "(import hipad_amd before torch); see hipad_amd/runtime_env.py" % runtime_env.REQUIRED)
         self.model, self.frames = model, frames
         self.inner = TrainStep(model, cfg, comm_dtype=comm_dtype, capturable=True)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
@@ -172,12 +180,16 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._feed(*frames.next())
+        if self.debug_hook is not None:
+            self.debug_hook("before_capture")
         self.graph_a = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_a):
             self.loss = self._fwd_bwd()
         self.graph_b = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
             self._update()
+        if self.debug_hook is not None:
+            self.debug_hook("after_capture")
         # the capture itself did not execute the work: replay once so the banks hold this frame's state
         self.graph_a.replay()
         self.inner.grads.all_reduce_mean()

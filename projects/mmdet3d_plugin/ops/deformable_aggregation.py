@@ -22,6 +22,23 @@ import os as _os
 _ATOMIC_FEAT = _os.environ.get("HIPAD_DAF_ATOMIC", "0") == "1"  # debugging aid: one-pass atomic scatter backward
 
 
+_CROSS_CHECK = _os.environ.get("HIPAD_DAF_CROSS_CHECK", "0") == "1"  # debugging aid, see _cross_check
+CROSS_CHECK_LOG = []  # per backward call site: device tensor [max|sorted-atomic|, max|atomic|, nonfinite flags]
+
+
+def _cross_check(feat, ss, st, loc, w, grad_output):
+    """Debugging aid (capturable): runs the feature gradient of this call through BOTH backward variants into
+    scratch buffers and records how far they are apart, plus finiteness of the inputs."""
+    a = torch.zeros_like(feat)
+    b = torch.zeros_like(feat)
+    _lib.daf_backward(feat, ss, st, loc, w, grad_output, a, None, None, atomic_feat=True)
+    _lib.daf_backward(feat, ss, st, loc, w, grad_output, b, None, None, atomic_feat=False)
+    rec = torch.stack([(a - b).abs().max(), a.abs().max(), (~torch.isfinite(b)).sum().float(),
+                       (~torch.isfinite(loc)).sum().float(), (~torch.isfinite(w)).sum().float(),
+                       (~torch.isfinite(grad_output)).sum().float()])
+    CROSS_CHECK_LOG.append((tuple(loc.shape), rec))
+
+
 def _as_i32(t):
     if t.dtype == torch.int32 and t.is_contiguous():
         return t
@@ -107,6 +124,8 @@ class DeformableAggregationFunction(Function):
             grad_token = torch.zeros((), dtype=feat.dtype, device=feat.device)
         elif need_feat:
             grad_feat = ret_feat = torch.zeros_like(feat)
+        if _CROSS_CHECK and grad_feat is not None:
+            _cross_check(feat, ss, st, loc, w, grad_output)
         _lib.daf_backward(feat, ss, st, loc, w, grad_output, grad_feat, grad_loc, grad_w, overwrite_loc_w=True,
                           atomic_feat=_ATOMIC_FEAT)
         return ret_feat, None, None, grad_loc, grad_w, grad_token

@@ -7,6 +7,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+import hipad_amd  # noqa: E402,F401  HIP runtime flags (graph replay) before torch is imported anywhere
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 if GOLDEN not in sys.path:
     sys.path.insert(0, GOLDEN)

@@ -2,6 +2,7 @@
 import os, sys, time, warnings
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 warnings.filterwarnings("ignore")
+import hipad_amd  # noqa: F401  HIP runtime flags before torch
 import torch
 from hipad_amd.frame import build_detector, SyntheticFrames, TrainStep
 plan = int(sys.argv[1]) if len(sys.argv) > 1 else 480
