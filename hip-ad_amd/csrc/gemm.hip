@@ -14,117 +14,124 @@
 //   backward: TWO kernels  dX = (dY o [Y>0]) W
 //                          dW += (dY o [Y>0])^T X ,  db += colsum(dY o [Y>0])   (atomic accumulation
 //                          straight into the caller's gradient buffers: no separate accumulate pass)
-// Tile: 64 x 64 outputs per 256-thread workgroup (2 x 2 waves, each 2 x 2 MFMA tiles), K step 32.
-// Both operands go through LDS as [out index][reduction index] bf16 rows (80-byte stride), which
+// Tile: 64 x 32 outputs per 256-thread workgroup, reduction in chunks of 256 (see below).
+// Both operands go through LDS as [out index][reduction index] bf16 rows (528-byte stride), which
 // makes the three products (NT, NN, TN) one code path with two tile loaders (reduction index
-// contiguous in memory, or strided = transposed on the way in).
+// contiguous in memory, or strided = transposed in registers on the way in).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "hipad.h"
+#include "daf_common.h"
 
 namespace hipad {
 
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int BM = 64, BN = 64, BK = 32;
-constexpr int LDS_STRIDE = BK + 8;  // bf16 elements per tile row (80 bytes: 16-byte aligned fragments)
+// Tile: 64 rows of A_op x 32 rows of B_op per 256-thread workgroup (4 waves, each 16 x 32 = two MFMA tiles),
+// reduction consumed in chunks of KC = 256: a whole chunk of both operands is fetched with ALL its loads in
+// flight at once (24-40 float4 per thread), rounded to bf16 into LDS, and multiplied with 8 MFMA steps.
+// The decoder's GEMMs are tiny (M <= 1500, K <= 1024, mostly 256 x 256) and latency-bound: one round trip
+// to memory per 256 of reduction instead of one per 32, and 2x the workgroups of a 64 x 64 tile.
+constexpr int BM = 64, BN = 32, KC = 256;
+constexpr int LDS_STRIDE = KC + 8;  // bf16 per tile row (528 bytes: 16-byte aligned fragments)
 
 __device__ __forceinline__ short to_bf16(float x) { return __builtin_bit_cast(short, (__bf16)x); }
 
-// Tile loader, reduction index CONTIGUOUS in memory: T[r][kk] = src[(r0 + r) * ld + k0 + kk]
-// optional gate: element is zeroed where gate[(r0 + r) * ld + k0 + kk] <= 0 (ReLU mask from Y).
-__device__ __forceinline__ void load_tile_rowmajor(short (*T)[LDS_STRIDE], const float *__restrict__ src,
-                                                   const float *__restrict__ gate, int ld, int r0, int k0,
-                                                   int rows, int kmax, int tid) {
-  const int r = tid >> 2, kk = (tid & 3) * 8;
-  const int gr = r0 + r, gk = k0 + kk;
-  short v[8];
-  const bool fast = gr < rows && gk + 8 <= kmax && (ld & 3) == 0;
-  if (fast) {
-    const float4 a = *reinterpret_cast<const float4 *>(src + (size_t)gr * ld + gk);
-    const float4 b = *reinterpret_cast<const float4 *>(src + (size_t)gr * ld + gk + 4);
-    float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    if (gate) {
-      const float4 c = *reinterpret_cast<const float4 *>(gate + (size_t)gr * ld + gk);
-      const float4 d = *reinterpret_cast<const float4 *>(gate + (size_t)gr * ld + gk + 4);
-      const float g[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
-#pragma unroll
-      for (int i = 0; i < 8; ++i) f[i] = g[i] > 0.f ? f[i] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = to_bf16(f[i]);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float f = 0.f;
-      if (gr < rows && gk + i < kmax) {
-        f = src[(size_t)gr * ld + gk + i];
-        if (gate && !(gate[(size_t)gr * ld + gk + i] > 0.f)) f = 0.f;
-      }
-      v[i] = to_bf16(f);
-    }
+// Four consecutive floats, branch-free: out-of-range elements read a clamped (valid) address and are
+// zeroed by a select, so every load of a chunk is issued before the first one is waited for.
+// VEC: p is 16-byte aligned and nvalid is 0 or 4 (guaranteed by the host when ld % 4 == 0).
+template <bool VEC>
+__device__ __forceinline__ float4 ld4(const float *__restrict__ p, const float *__restrict__ safe, int nvalid) {
+  const float *q = nvalid > 0 ? p : safe;
+  if (VEC) {
+    const float4 v = *reinterpret_cast<const float4 *>(q);
+    return nvalid > 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  bf16x8 pk;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) pk[i] = v[i];
-  *reinterpret_cast<bf16x8 *>(&T[r][kk]) = pk;
+  const float x = q[0], y = q[nvalid > 1 ? 1 : 0], z = q[nvalid > 2 ? 2 : 0], w = q[nvalid > 3 ? 3 : 0];
+  return make_float4(nvalid > 0 ? x : 0.f, nvalid > 1 ? y : 0.f, nvalid > 2 ? z : 0.f, nvalid > 3 ? w : 0.f);
 }
 
-// Tile loader, reduction index STRIDED in memory: T[r][kk] = src[(k0 + kk) * ld + r0 + r]
-__device__ __forceinline__ void load_tile_transposed(short (*T)[LDS_STRIDE], const float *__restrict__ src,
-                                                     const float *__restrict__ gate, int ld, int r0, int k0,
-                                                     int rows, int kmax, int tid) {
-  const int kk = tid >> 3, r = (tid & 7) * 8;
-  const int gk = k0 + kk, gr = r0 + r;
-  float f[8];
-  const bool fast = gk < kmax && gr + 8 <= rows && (ld & 3) == 0;
-  if (fast) {
-    const float4 a = *reinterpret_cast<const float4 *>(src + (size_t)gk * ld + gr);
-    const float4 b = *reinterpret_cast<const float4 *>(src + (size_t)gk * ld + gr + 4);
-    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
-    if (gate) {
-      const float4 c = *reinterpret_cast<const float4 *>(gate + (size_t)gk * ld + gr);
-      const float4 d = *reinterpret_cast<const float4 *>(gate + (size_t)gk * ld + gr + 4);
-      const float g[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
-#pragma unroll
-      for (int i = 0; i < 8; ++i) f[i] = g[i] > 0.f ? f[i] : 0.f;
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      f[i] = 0.f;
-      if (gk < kmax && gr + i < rows) {
-        f[i] = src[(size_t)gk * ld + gr + i];
-        if (gate && !(gate[(size_t)gk * ld + gr + i] > 0.f)) f[i] = 0.f;
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) T[r + i][kk] = to_bf16(f[i]);
+__device__ __forceinline__ float4 gate4(float4 v, float4 g) {
+  return make_float4(g.x > 0.f ? v.x : 0.f, g.y > 0.f ? v.y : 0.f, g.z > 0.f ? v.z : 0.f, g.w > 0.f ? v.w : 0.f);
 }
 
-__device__ __forceinline__ void mma_step(f32x4 (&acc)[2][2], short (*TA)[LDS_STRIDE], short (*TB)[LDS_STRIDE],
-                                         int wm, int wn, int l15, int quad) {
-  bf16x8 a[2], b[2];
+__device__ __forceinline__ bf16x8 pack8(float a, float b, float c, float d, float e, float f, float g, float h) {
+  bf16x8 p;
+  p[0] = to_bf16(a); p[1] = to_bf16(b); p[2] = to_bf16(c); p[3] = to_bf16(d);
+  p[4] = to_bf16(e); p[5] = to_bf16(f); p[6] = to_bf16(g); p[7] = to_bf16(h);
+  return p;
+}
+
+// ---- operand chunk, reduction index CONTIGUOUS in memory: T[r][kk] = src[(r0 + r) * ld + k0 + kk]
+// thread -> 8 consecutive kk (kq = tid & 31), rows rr + 8 p (rr = tid >> 5): a wave reads 2 x 1 KiB rows.
+template <int ROWS, bool VEC>
+__device__ __forceinline__ void gload_rowmajor(float4 (&v)[ROWS / 4], const float *__restrict__ src, int ld, int r0,
+                                               int k0, int rows, int kend, int tid) {
+  const int kk = (tid & 31) * 8, rr = tid >> 5;
+  const int gk = k0 + kk;
+  const int n0 = max(0, min(4, kend - gk)), n1 = max(0, min(4, kend - gk - 4));
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    a[i] = *reinterpret_cast<const bf16x8 *>(&TA[wm * 32 + 16 * i + l15][8 * quad]);
-    b[i] = *reinterpret_cast<const bf16x8 *>(&TB[wn * 32 + 16 * i + l15][8 * quad]);
+  for (int p = 0; p < ROWS / 8; ++p) {
+    const int gr = r0 + rr + 8 * p;
+    const bool in = gr < rows;
+    const float *q = src + (size_t)(in ? gr : 0) * ld + gk;
+    v[2 * p] = ld4<VEC>(q, src, in ? n0 : 0);
+    v[2 * p + 1] = ld4<VEC>(q + 4, src, in ? n1 : 0);
   }
+}
+template <int ROWS>
+__device__ __forceinline__ void lstore_rowmajor(short (*T)[LDS_STRIDE], const float4 (&v)[ROWS / 4], int tid) {
+  const int kk = (tid & 31) * 8, rr = tid >> 5;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int p = 0; p < ROWS / 8; ++p) {
+    const float4 a = v[2 * p], b = v[2 * p + 1];
+    *reinterpret_cast<bf16x8 *>(&T[rr + 8 * p][kk]) = pack8(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
+  }
+}
+
+// ---- operand chunk, reduction index STRIDED in memory: T[r][kk] = src[(k0 + kk) * ld + r0 + r]
+// thread -> blocks of 4 r x 8 kk (8 float4 loads along r, transposed in registers, 4 16-byte LDS stores)
+template <int ROWS, bool VEC>
+__device__ __forceinline__ void gload_trans(float4 (&v)[ROWS / 4], const float *__restrict__ src, int ld, int r0, int k0,
+                                            int rows, int kend, int tid) {
+  constexpr int RG = ROWS / 4;  // r-groups per tile
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+  for (int j = 0; j < ROWS / 32; ++j) {
+    const int id = tid + 256 * j;
+    const int rg = id % RG, kg = id / RG;
+    const int gr = r0 + 4 * rg;
+    const int nr = max(0, min(4, rows - gr));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int gk = k0 + 8 * kg + i;
+      const bool in = gk < kend;
+      v[8 * j + i] = ld4<VEC>(src + (size_t)(in ? gk : 0) * ld + (nr > 0 ? gr : 0), src, in ? nr : 0);
+    }
+  }
+}
+template <int ROWS>
+__device__ __forceinline__ void lstore_trans(short (*T)[LDS_STRIDE], const float4 (&v)[ROWS / 4], int tid) {
+  constexpr int RG = ROWS / 4;
+#pragma unroll
+  for (int j = 0; j < ROWS / 32; ++j) {
+    const int id = tid + 256 * j;
+    const int rg = id % RG, kg = id / RG;
+    const float4 *w = &v[8 * j];
+    *reinterpret_cast<bf16x8 *>(&T[4 * rg + 0][8 * kg]) = pack8(w[0].x, w[1].x, w[2].x, w[3].x, w[4].x, w[5].x, w[6].x, w[7].x);
+    *reinterpret_cast<bf16x8 *>(&T[4 * rg + 1][8 * kg]) = pack8(w[0].y, w[1].y, w[2].y, w[3].y, w[4].y, w[5].y, w[6].y, w[7].y);
+    *reinterpret_cast<bf16x8 *>(&T[4 * rg + 2][8 * kg]) = pack8(w[0].z, w[1].z, w[2].z, w[3].z, w[4].z, w[5].z, w[6].z, w[7].z);
+    *reinterpret_cast<bf16x8 *>(&T[4 * rg + 3][8 * kg]) = pack8(w[0].w, w[1].w, w[2].w, w[3].w, w[4].w, w[5].w, w[6].w, w[7].w);
+  }
 }
 
 // C[m][n] = sum_k A_op[m][k] * B_op[n][k]
 //   A_TRANS: A_op[m][k] = A[k * lda + m]  else A[m * lda + k]   (optional ReLU gate on A, same layout)
 //   B_TRANS: B_op[n][k] = B[k * ldb + n]  else B[n * ldb + k]
-//   EPI 0: C = relu?(acc + bias[n])  stored;   EPI 1: atomicAdd(C, acc) + optional column sums of A_op
-//   grid = (ceil(N/64), ceil(M/64), splits over the reduction)
-template <bool A_TRANS, bool B_TRANS, int EPI>
+//   EPI 0: C = relu?(acc + bias[n])  stored;   EPI 1: atomicAdd(C, acc) + optional row sums of A_op
+//   grid = (ceil(N/32), ceil(M/64), splits over the reduction); k_per_split is a multiple of KC
+template <bool A_TRANS, bool B_TRANS, int EPI, bool VA, bool VB>
 __global__ __launch_bounds__(256) void gemm_kernel(float *__restrict__ C, const float *__restrict__ A,
                                                    const float *__restrict__ A_gate, const float *__restrict__ B,
                                                    const float *__restrict__ bias, float *__restrict__ rowsum_out,
@@ -134,52 +141,95 @@ __global__ __launch_bounds__(256) void gemm_kernel(float *__restrict__ C, const 
   __shared__ short TB[BN][LDS_STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int l15 = lane & 15, quad = lane >> 4;
-  const int wm = wv >> 1, wn = wv & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
-  f32x4 acc[2][2];
+  f32x4 acc[2];
+  acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float rsum = 0.f;
+
+  float4 ra[BM / 4], rb[BN / 4];
+  auto fetch = [&](int k0) {
+    if (A_TRANS) gload_trans<BM, VA>(ra, A, lda, m0, k0, M, kend, tid);
+    else gload_rowmajor<BM, VA>(ra, A, lda, m0, k0, M, kend, tid);
+    if (A_gate) {
+      float4 rg[BM / 4];
+      if (A_TRANS) gload_trans<BM, VA>(rg, A_gate, lda, m0, k0, M, kend, tid);
+      else gload_rowmajor<BM, VA>(rg, A_gate, lda, m0, k0, M, kend, tid);
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float rsum = 0.f;  // EPI 1: sum over the reduction of A_op[m = m0 + tid][.] for tid < 64
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    if (A_TRANS) load_tile_transposed(TA, A, A_gate, lda, m0, k0, M, kend, tid);
-    else load_tile_rowmajor(TA, A, A_gate, lda, m0, k0, M, kend, tid);
-    if (B_TRANS) load_tile_transposed(TB, B, nullptr, ldb, n0, k0, N, kend, tid);
-    else load_tile_rowmajor(TB, B, nullptr, ldb, n0, k0, N, kend, tid);
+      for (int i = 0; i < BM / 4; ++i) ra[i] = gate4(ra[i], rg[i]);
+    }
+    if (B_TRANS) gload_trans<BN, VB>(rb, B, ldb, n0, k0, N, kend, tid);
+    else gload_rowmajor<BN, VB>(rb, B, ldb, n0, k0, N, kend, tid);
+  };
+
+  fetch(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += KC) {
+    if (A_TRANS) lstore_trans<BM>(TA, ra, tid); else lstore_rowmajor<BM>(TA, ra, tid);
+    if (B_TRANS) lstore_trans<BN>(TB, rb, tid); else lstore_rowmajor<BN>(TB, rb, tid);
     __syncthreads();
-    mma_step(acc, TA, TB, wm, wn, l15, quad);
-    if (EPI == 1 && rowsum_out && blockIdx.x == 0 && tid < BM) {
+    if (k0 + KC < kend) fetch(k0 + KC);  // next chunk's loads fly during the MFMA phase
+    const int nsteps = (min(KC, kend - k0) + 31) >> 5;
+    for (int s = 0; s < nsteps; ++s) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&TA[16 * wv + l15][32 * s + 8 * quad]);
+      const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(&TB[l15][32 * s + 8 * quad]);
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(&TB[16 + l15][32 * s + 8 * quad]);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, acc[1], 0, 0, 0);
+    }
+    if (EPI == 1 && rowsum_out && blockIdx.x == 0) {
+      // sum over the chunk of A_op[row = tid/4][.]: each thread a quarter of the row, then 2 shuffles
+      const int row = tid >> 2, q = tid & 3;
+      float s8 = 0.f;
 #pragma unroll
-      for (int kk = 0; kk < BK; ++kk) rsum += (float)__builtin_bit_cast(__bf16, TA[tid][kk]);
+      for (int i = 0; i < KC / 32; ++i) {
+        const bf16x8 t = *reinterpret_cast<const bf16x8 *>(&TA[row][64 * q + 8 * i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s8 += (float)__builtin_bit_cast(__bf16, (short)t[e]);
+      }
+      s8 += __shfl_xor(s8, 1);
+      s8 += __shfl_xor(s8, 2);
+      rsum += s8;
     }
     __syncthreads();
   }
-  // C fragment: row = m0 + 32 wm + 16 i + 4 quad + r ; col = n0 + 32 wn + 16 j + l15
+  // C fragment j: row = m0 + 16 wv + 4 quad + r ; col = n0 + 16 j + l15
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + 16 * j + l15;
+    if (col >= N) continue;
+    const float bv = (EPI == 0 && bias) ? bias[col] : 0.f;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + 32 * wn + 16 * j + l15;
-      if (col >= N) continue;
-      const float bv = (EPI == 0 && bias) ? bias[col] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + 32 * wm + 16 * i + 4 * quad + r;
-        if (row >= M) continue;
-        float v = acc[i][j][r];
-        if (EPI == 0) {
-          v += bv;
-          if (relu) v = fmaxf(v, 0.f);
-          C[(size_t)row * ldc + col] = v;
-        } else {
-          atomicAdd(C + (size_t)row * ldc + col, v);
-        }
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + 16 * wv + 4 * quad + r;
+      if (row >= M) continue;
+      float v = acc[j][r];
+      if (EPI == 0) {
+        v += bv;
+        if (relu) v = fmaxf(v, 0.f);
+        C[(size_t)row * ldc + col] = v;
+      } else {
+        atomicAdd(C + (size_t)row * ldc + col, v);
       }
     }
-  if (EPI == 1 && rowsum_out && blockIdx.x == 0 && tid < BM && m0 + tid < M) atomicAdd(rowsum_out + m0 + tid, rsum);
+  }
+  if (EPI == 1 && rowsum_out && blockIdx.x == 0 && (tid & 3) == 0 && m0 + (tid >> 2) < M)
+    atomicAdd(rowsum_out + m0 + (tid >> 2), rsum);
 }
+
+static inline int vec_ok(const void *p, int ld) { return (((uintptr_t)p & 15) == 0 && (ld & 3) == 0) ? 1 : 0; }
+
+// launch gemm_kernel<AT, BT, EPI, va, vb> with the two vector-load flags resolved at run time
+#define HIPAD_GEMM(AT, BT, EPI, va, vb, grid, stream, ...)                                                      \
+  do {                                                                                                          \
+    if (va) {                                                                                                   \
+      if (vb) hipLaunchKernelGGL((gemm_kernel<AT, BT, EPI, true, true>), grid, dim3(256), 0, stream, __VA_ARGS__);   \
+      else hipLaunchKernelGGL((gemm_kernel<AT, BT, EPI, true, false>), grid, dim3(256), 0, stream, __VA_ARGS__);     \
+    } else {                                                                                                    \
+      if (vb) hipLaunchKernelGGL((gemm_kernel<AT, BT, EPI, false, true>), grid, dim3(256), 0, stream, __VA_ARGS__);  \
+      else hipLaunchKernelGGL((gemm_kernel<AT, BT, EPI, false, false>), grid, dim3(256), 0, stream, __VA_ARGS__);    \
+    }                                                                                                           \
+  } while (0)
 
 static int check_lin(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return HIPAD_EINVAL;
@@ -200,9 +250,10 @@ int hipad_linear_forward(float *y, const float *x, const float *weight, const fl
   if (rc != HIPAD_OK) return rc;
   if (!y || !x || !weight) return HIPAD_EINVAL;
   const dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, 1);
+  const int kall = (K + KC - 1) / KC * KC;
   // C[m][n] = sum_k X[m][k] W[n][k]
-  hipLaunchKernelGGL((gemm_kernel<false, false, 0>), grid, dim3(256), 0, (hipStream_t)stream, y, x,
-                     (const float *)nullptr, weight, bias, (float *)nullptr, M, N, K, K, K, N, relu, K);
+  HIPAD_GEMM(false, false, 0, vec_ok(x, K), vec_ok(weight, K), grid, (hipStream_t)stream, y, x,
+             (const float *)nullptr, weight, bias, (float *)nullptr, M, N, K, K, K, N, relu, kall);
   return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
 }
 
@@ -212,32 +263,39 @@ int hipad_linear_backward(float *dx, float *dw, float *db, const float *dy, cons
   if (rc != HIPAD_OK) return rc;
   if (!dy || !x || !weight) return HIPAD_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
+  const int vdy = vec_ok(dy, N) & (y_relu ? vec_ok(y_relu, N) : 1);
   if (dx) {
     // dX[m][k] = sum_n dYm[m][n] W[n][k]  : A = dY (row-major over n), B_op[k][n] = W[n*K + k] (transposed)
-    const dim3 grid((K + BN - 1) / BN, (M + BM - 1) / BM, 1);
-    hipLaunchKernelGGL((gemm_kernel<false, true, 0>), grid, dim3(256), 0, stream, dx, dy, y_relu, weight,
-                       (const float *)nullptr, (float *)nullptr, M, K, N, N, K, K, 0, N);
+    const int tiles = ((K + BN - 1) / BN) * ((M + BM - 1) / BM);
+    int splits = 1;
+    if (N > 4 * KC) {  // long reduction (the 256 -> 9600 / 2880 weight layers): split it, accumulate atomically
+      splits = (N + 2 * KC - 1) / (2 * KC);
+      while (splits > 1 && (long long)tiles * splits > 4096) --splits;
+    }
+    int per = (N + splits - 1) / splits;
+    per = (per + KC - 1) / KC * KC;
+    splits = (N + per - 1) / per;
+    const dim3 grid((K + BN - 1) / BN, (M + BM - 1) / BM, splits);
+    if (splits == 1) {
+      HIPAD_GEMM(false, true, 0, vdy, vec_ok(weight, K), grid, stream, dx, dy, y_relu, weight,
+                 (const float *)nullptr, (float *)nullptr, M, K, N, N, K, K, 0, per);
+    } else {
+      if (fill_zero(dx, (size_t)M * K * sizeof(float), stream) != HIPAD_OK) return HIPAD_ELAUNCH;
+      HIPAD_GEMM(false, true, 1, vdy, vec_ok(weight, K), grid, stream, dx, dy, y_relu, weight,
+                 (const float *)nullptr, (float *)nullptr, M, K, N, N, K, K, 0, per);
+    }
   }
   if (dw || db) {
+    if (!dw) return HIPAD_EINVAL;  // bias gradient alone is not needed by the model (see functional._Linear)
     // dW[n][k] += sum_m dYm[m][n] X[m][k] : A_op[n][m] = dY[m*N + n] (transposed), B_op[k][m] = X[m*K + k]
-    // the reduction runs over the M rows: split it so that enough workgroups exist
+    // the reduction runs over the M rows: one chunk of KC rows per workgroup unless that makes too many
     const int tiles = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
-    int splits = (1024 + tiles - 1) / tiles;
-    const int max_splits = (M + 4 * BK - 1) / (4 * BK);
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    int per = (M + splits - 1) / splits;
-    per = (per + BK - 1) / BK * BK;
-    splits = (M + per - 1) / per;
-    if (dw) {
-      const dim3 grid((K + BN - 1) / BN, (N + BM - 1) / BM, splits);
-      hipLaunchKernelGGL((gemm_kernel<true, true, 1>), grid, dim3(256), 0, stream, dw, dy, y_relu, x,
-                         (const float *)nullptr, db, N, K, M, N, K, K, 0, per);
-    } else {
-      // bias gradient alone (weight frozen): same kernel with a 1-column dummy product is wasteful;
-      // not needed by the model (every Linear with a bias also trains its weight)
-      return HIPAD_EINVAL;
-    }
+    int per = KC;
+    while ((long long)tiles * ((M + per - 1) / per) > 4096 && per < M) per += KC;
+    const int splits = (M + per - 1) / per;
+    const dim3 grid((K + BN - 1) / BN, (N + BM - 1) / BM, splits);
+    HIPAD_GEMM(true, true, 1, vdy, vec_ok(x, K), grid, stream, dw, dy, y_relu, x,
+               (const float *)nullptr, db, N, K, M, N, K, K, 0, per);
   }
   return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
 }
