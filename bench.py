@@ -228,8 +228,7 @@ class Stage2Full:
             e[2].record()
             loss.backward()
             self.train_step.grads.check_views()
-            torch.nn.utils.clip_grad_norm_(self.train_step.params, self.train_step.max_norm, foreach=True)
-            self.train_step.opt.step()
+            self.train_step.update()
             e[3].record()
             e[3].synchronize()
             acc["encoder_fwd"] += e[0].elapsed_time(e[1]) / reps

@@ -1,0 +1,139 @@
+// hip-ad_amd/csrc/optim.hip -- gradient clipping + AdamW over ONE flat parameter buffer.
+//
+// Replaces: the optimiser step of the reference's training loop -- torch AdamW (lr 2e-4, weight decay 1e-3,
+// backbone lr x0.5; projects/configs/hipad_b2d_stage2.py:629-641) preceded by clip_grad_norm_(max_norm=25)
+// (optimizer_config.grad_clip), which mmcv's OptimizerHook runs per parameter tensor.  With ~2000 parameter
+// tensors torch's multi-tensor path needs ~170 launches and 6.5 ms per step (rocprofv3, profiles/); here all
+// parameters / gradients / moments are views into four flat fp32 buffers and a step is two launches that
+// move the compulsory 32 bytes per element once (~0.7 ms for 97 M parameters at HBM speed).
+//
+//   sqnorm kernel : partial[b] = sum of g^2 over the block's span      (deterministic two-level sum)
+//   adamw kernel  : every block re-reduces the partials (4 KiB, L2), derives the clip coefficient
+//                   c = min(1, max_norm / (norm + 1e-6)) -- torch.nn.utils.clip_grad_norm_ -- and applies
+//                       g' = c g ; p *= 1 - lr wd ; m = b1 m + (1 - b1) g' ; v = b2 v + (1 - b2) g'^2
+//                       p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+//                   -- torch.optim.AdamW -- with lr = lr0 for elements < n_group0 and lr1 after, then
+//                   optionally zeroes g for the next step.  The step count t lives on the device
+//                   (incremented here), so the whole thing replays from a hipGraph.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hipad.h"
+
+namespace hipad {
+
+constexpr int kNormBlocks = 1024;
+
+__device__ __forceinline__ float block_sum_256(float v, float *sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) sh[wv] = v;
+  __syncthreads();
+  v = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return v;
+}
+
+__global__ __launch_bounds__(256) void grad_sqnorm_kernel(float *__restrict__ partial, const float *__restrict__ g,
+                                                          long n4 /* float4 count */, long n) {
+  __shared__ float sh[4];
+  const float4 *g4 = reinterpret_cast<const float4 *>(g);
+  float s = 0.f;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 x = g4[i];
+    s += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+  }
+  if (blockIdx.x == 0) {  // tail (n not a multiple of 4)
+    for (long i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) s += g[i] * g[i];
+  }
+  s = block_sum_256(s, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+struct AdamCoef {
+  float lr0, lr1, beta1, beta2, eps, wd, max_norm;
+};
+
+__device__ __forceinline__ void adam_elem(float &p, float &g, float &m, float &v, float lr, float c, float b1, float b2,
+                                          float eps, float wd, float inv_bc1, float inv_sqrt_bc2) {
+  const float gg = g * c;
+  p *= 1.f - lr * wd;
+  m = b1 * m + (1.f - b1) * gg;
+  v = b2 * v + (1.f - b2) * gg * gg;
+  const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
+  p -= lr * inv_bc1 * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adamw_flat_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
+                                                         float *__restrict__ v, long n, long n_group0,
+                                                         const float *__restrict__ partial, int *__restrict__ step,
+                                                         float *__restrict__ norm_out, AdamCoef k, int zero_grad) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < kNormBlocks; i += 256) s += partial[i];
+  s = block_sum_256(s, sh);
+  const float norm = sqrtf(s);
+  float c = 1.f;
+  if (k.max_norm > 0.f) c = fminf(1.f, k.max_norm / (norm + 1e-6f));
+  const int t = *step + 1;  // every block reads the same (old) value; block 0 publishes the new one last
+  const float inv_bc1 = 1.f / (1.f - powf(k.beta1, (float)t));
+  const float inv_sqrt_bc2 = 1.f / sqrtf(1.f - powf(k.beta2, (float)t));
+  const long n4 = n >> 2;
+  float4 *p4 = reinterpret_cast<float4 *>(p), *g4 = reinterpret_cast<float4 *>(g);
+  float4 *m4 = reinterpret_cast<float4 *>(m), *v4 = reinterpret_cast<float4 *>(v);
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 P = p4[i], G = g4[i], Mv = m4[i], V = v4[i];
+    const long e = i * 4;
+    const float l0 = e + 0 < n_group0 ? k.lr0 : k.lr1, l1 = e + 1 < n_group0 ? k.lr0 : k.lr1;
+    const float l2 = e + 2 < n_group0 ? k.lr0 : k.lr1, l3 = e + 3 < n_group0 ? k.lr0 : k.lr1;
+    adam_elem(P.x, G.x, Mv.x, V.x, l0, c, k.beta1, k.beta2, k.eps, k.wd, inv_bc1, inv_sqrt_bc2);
+    adam_elem(P.y, G.y, Mv.y, V.y, l1, c, k.beta1, k.beta2, k.eps, k.wd, inv_bc1, inv_sqrt_bc2);
+    adam_elem(P.z, G.z, Mv.z, V.z, l2, c, k.beta1, k.beta2, k.eps, k.wd, inv_bc1, inv_sqrt_bc2);
+    adam_elem(P.w, G.w, Mv.w, V.w, l3, c, k.beta1, k.beta2, k.eps, k.wd, inv_bc1, inv_sqrt_bc2);
+    p4[i] = P; m4[i] = Mv; v4[i] = V;
+    if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (blockIdx.x == 0) {
+    for (long i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
+      float P = p[i], G = g[i], Mv = m[i], V = v[i];
+      adam_elem(P, G, Mv, V, i < n_group0 ? k.lr0 : k.lr1, c, k.beta1, k.beta2, k.eps, k.wd, inv_bc1, inv_sqrt_bc2);
+      p[i] = P; m[i] = Mv; v[i] = V;
+      if (zero_grad) g[i] = 0.f;
+    }
+  }
+  // the step counter is bumped by a trailing one-thread kernel (adamw_bump_kernel): blocks of THIS grid may
+  // still be reading *step when block 0 gets here
+  if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) *norm_out = norm;
+}
+
+__global__ void adamw_bump_kernel(int *step) { *step += 1; }
+
+}  // namespace hipad
+
+using namespace hipad;
+
+extern "C" {
+
+size_t hipad_adamw_workspace(void) { return kNormBlocks * sizeof(float); }
+
+int hipad_adamw_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, long long n, long long n_group0,
+                     float lr0, float lr1, float beta1, float beta2, float eps, float weight_decay, float max_norm,
+                     int *step_dev, float *norm_out_dev, void *workspace, size_t workspace_bytes, int zero_grad,
+                     hipad_stream_t stream_) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev || n <= 0) return HIPAD_EINVAL;
+  if (!workspace || workspace_bytes < hipad_adamw_workspace()) return HIPAD_EWORKSPACE;
+  if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0) return HIPAD_EINVAL;
+  hipStream_t stream = (hipStream_t)stream_;
+  float *partial = (float *)workspace;
+  hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(kNormBlocks), dim3(256), 0, stream, partial, grad, (long)(n >> 2), (long)n);
+  AdamCoef k{lr0, lr1, beta1, beta2, eps, weight_decay, max_norm};
+  hipLaunchKernelGGL(adamw_flat_kernel, dim3(2048), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, (long)n,
+                     (long)n_group0, (const float *)partial, step_dev, norm_out_dev, k, zero_grad);
+  hipLaunchKernelGGL(adamw_bump_kernel, dim3(1), dim3(1), 0, stream, step_dev);
+  return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
+}
+
+}  // extern "C"

@@ -29,21 +29,28 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
-class FlatGrads:
-    """All gradients of ``params`` as views into one contiguous buffer."""
+def flat_offsets(params, align=64):
+    """Start offset of every tensor in a flat buffer, each aligned to ``align`` elements (256 bytes for fp32:
+    the GEMM kernels vector-load weights, and padding keeps gradient and parameter offsets identical)."""
+    offs, off = [], 0
+    for p in params:
+        offs.append(off)
+        off += (p.numel() + align - 1) // align * align
+    return offs, off
 
-    def __init__(self, params, comm_dtype=None):
+
+class FlatGrads:
+    """All gradients of ``params`` as views into one contiguous buffer (offsets: ``flat_offsets``)."""
+
+    def __init__(self, params, comm_dtype=None, align=64):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
         ref = self.params[0]
-        total = sum(p.numel() for p in self.params)
+        self.offsets, total = flat_offsets(self.params, align)
         self.flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
-            off += n
+        for p, off in zip(self.params, self.offsets):
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
         self.comm_dtype = comm_dtype
         self._comm = torch.empty(total, dtype=comm_dtype, device=ref.device) if comm_dtype not in (None, ref.dtype) else None
 
@@ -52,15 +59,13 @@ class FlatGrads:
 
     def check_views(self):
         """Autograd may replace .grad when it was set to None in between; re-attach if so."""
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             n = p.numel()
             if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + off * self.flat.element_size():
                 g = p.grad
                 p.grad = self.flat[off:off + n].view_as(p)
                 if g is not None:
                     p.grad.copy_(g)
-            off += n
 
     def all_reduce_mean(self, group=None):
         """Average the flat gradient over the ranks with one collective."""

@@ -81,7 +81,8 @@ class TrainStep:
     projects/configs/hipad_b2d_stage2.py:629-641; data parallel as apis/mmdet_train.py:97-102)."""
 
     def __init__(self, model, cfg, comm_dtype=None, capturable=False):
-        from .dist import FlatGrads, broadcast_parameters
+        from .dist import broadcast_parameters
+        from .optim import FlatAdamW
         self.model = model
         broadcast_parameters(model)
         opt = cfg["optimizer"]
@@ -89,11 +90,17 @@ class TrainStep:
         bb = [p for n, p in named if n.startswith("img_backbone")]
         rest = [p for n, p in named if not n.startswith("img_backbone")]
         mult = opt["paramwise_cfg"]["custom_keys"]["img_backbone"]["lr_mult"]
-        self.params = rest + bb
-        self.grads = FlatGrads(self.params, comm_dtype=comm_dtype)
-        self.opt = torch.optim.AdamW([dict(params=rest, lr=opt["lr"]), dict(params=bb, lr=opt["lr"] * mult)],
-                                     lr=opt["lr"], weight_decay=opt["weight_decay"], fused=True, capturable=capturable)
         self.max_norm = cfg["optimizer_config"]["grad_clip"]["max_norm"]
+        # parameters, gradients and AdamW moments in flat buffers; clip + step = two launches
+        self.opt = FlatAdamW([(rest, opt["lr"]), (bb, opt["lr"] * mult)], weight_decay=opt["weight_decay"],
+                             max_norm=self.max_norm, comm_dtype=comm_dtype)
+        self.params = self.opt.params
+        self.grads = self.opt.grads
+
+    @property
+    def grad_norm(self):
+        """Total gradient norm before clipping of the last update (device scalar)."""
+        return self.opt.grad_norm
 
     def forward_backward(self, img, data):
         loss = _frame_loss(self.model, img, data)
@@ -101,15 +108,11 @@ class TrainStep:
         return loss
 
     def update(self):
-        # total norm BEFORE clipping, kept as a device scalar (read it for sanity checks: a captured step
-        # that computes garbage gradients still "trains" once they are clipped)
-        self.grad_norm = torch.nn.utils.clip_grad_norm_(self.params, self.max_norm, foreach=True)
-        self.opt.step()
+        self.opt.step(zero_grad=True)  # the kernel clears each gradient once it has been applied
 
     def __call__(self, img, data):
         from . import functional as HF
-        self.grads.zero()
-        loss = self.forward_backward(img, data)
+        loss = self.forward_backward(img, data)  # gradients are zero here: update() clears what it applied
         self.grads.check_views()
         self.grads.all_reduce_mean()
         self.update()
@@ -217,7 +220,7 @@ class GraphedTrainStep:
         return torch.full((self.frames.bs,), 0.5 * (self.frames.step - 1), dtype=torch.float64)
 
     def _fwd_bwd(self):
-        self.inner.grads.zero()
+        # gradients start at zero: FlatGrads allocates them so and every update() clears them again
         loss = _frame_loss(self.model, self.img, self.data)
         loss.backward()
         return loss

@@ -29,6 +29,9 @@ SIGNATURES = {
     "hipad_weights_softmax_backward": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p]),
     "hipad_linear_forward": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "hipad_linear_backward": (c_int, [c_void_p] * 7 + [c_int] * 3 + [c_void_p]),
+    "hipad_adamw_workspace": (c_size_t, []),
+    "hipad_adamw_step": (c_int, [c_void_p] * 4 + [ctypes.c_longlong] * 2 + [ctypes.c_float] * 7
+                         + [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "hipad_attention_forward": (c_int, [c_void_p] * 5 + [c_int] * 5 + [ctypes.c_float, ctypes.c_float, ctypes.c_uint,
                                                                      c_void_p, c_void_p]),
     "hipad_attention_backward": (c_int, [c_void_p] * 10 + [c_int] * 5 + [ctypes.c_float, ctypes.c_float,
@@ -298,3 +301,23 @@ def linear_backward(dy2, y_relu, x2, weight, dx, dw, db):
         st = lib.hipad_linear_backward(_ptr(dx), _ptr(dw), _ptr(db), dy2.data_ptr(), _ptr(y_relu), x2.data_ptr(),
                                        weight.data_ptr(), M, N, K, stream_ptr(x2.device))
     check(st, "hipad_linear_backward")
+
+
+def adamw_step(param, grad, exp_avg, exp_avg_sq, n_group0, lr0, lr1, betas, eps, weight_decay, max_norm, step_dev,
+               norm_out, workspace, zero_grad=True):
+    """Clip (global norm) + AdamW over flat fp32 buffers; see include/hipad.h."""
+    lib = load()
+    for t, nm in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _req(t, torch.float32, nm)
+    n = param.numel()
+    if not (grad.numel() == exp_avg.numel() == exp_avg_sq.numel() == n):
+        raise HipadError("adamw_step: buffers differ in length")
+    if step_dev.dtype != torch.int32 or not step_dev.is_cuda:
+        raise HipadError("adamw_step: step_dev must be a device int32 tensor")
+    with torch.cuda.device(param.device):
+        st = lib.hipad_adamw_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), n,
+                                  int(n_group0), float(lr0), float(lr1), float(betas[0]), float(betas[1]), float(eps),
+                                  float(weight_decay), float(max_norm if max_norm else 0.0), step_dev.data_ptr(),
+                                  _ptr(norm_out), workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                                  int(bool(zero_grad)), stream_ptr(param.device))
+    check(st, "hipad_adamw_step")

@@ -201,6 +201,25 @@ int hipad_linear_forward(float *y, const float *x, const float *weight, const fl
 int hipad_linear_backward(float *dx, float *dw, float *db, const float *dy, const float *y_relu,
                           const float *x, const float *weight, int M, int N, int K, hipad_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Gradient clipping + AdamW over flat buffers (hip-ad_amd/csrc/optim.hip).
+ * Replaces: the per-tensor optimiser step of the reference's training loop: mmcv OptimizerHook
+ *           grad_clip (max_norm 25) + torch.optim.AdamW with the backbone at lr x0.5
+ *           (projects/configs/hipad_b2d_stage2.py:629-641).
+ *   param / grad / exp_avg / exp_avg_sq: n floats each, 16-byte aligned; elements [0, n_group0) step
+ *   with lr0, the rest with lr1.  max_norm <= 0 disables clipping.  step_dev: device int32 holding the
+ *   number of steps taken so far (incremented here).  norm_out_dev (may be NULL): receives the total
+ *   gradient norm BEFORE clipping.  zero_grad != 0 clears grad after it has been consumed.
+ *   workspace: hipad_adamw_workspace() bytes of device scratch.
+ * Arithmetic is torch.nn.utils.clip_grad_norm_ followed by torch.optim.AdamW (decoupled weight decay,
+ * bias-corrected moments), fp32.
+ * ---------------------------------------------------------------------------------- */
+size_t hipad_adamw_workspace(void);
+int hipad_adamw_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, long long n,
+                     long long n_group0, float lr0, float lr1, float beta1, float beta2, float eps,
+                     float weight_decay, float max_norm, int *step_dev, float *norm_out_dev,
+                     void *workspace, size_t workspace_bytes, int zero_grad, hipad_stream_t stream);
+
 /* Tuning knob (host side, process-wide): target number of (point, camera) pairs one
  * wavefront owns in the forward / backward kernels.  <=0 restores the default. */
 void hipad_daf_set_pairs_per_wave(int fwd, int bwd);

@@ -1,0 +1,51 @@
+"""Flat clip + AdamW kernel (hip-ad_amd/csrc/optim.hip) against torch.nn.utils.clip_grad_norm_ +
+torch.optim.AdamW with two learning-rate groups, several steps, with and without clipping being active."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def make_params(seed):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(37, 5), (256, 256), (3,), (64, 3, 7, 7), (1,), (130,), (48, 33)]
+    return [torch.nn.Parameter(torch.randn(*s, generator=g).cuda()) for s in shapes]
+
+
+@pytest.mark.parametrize("max_norm", [0.5, 1e6, None])
+def test_flat_adamw_matches_torch(max_norm):
+    from hipad_amd.optim import FlatAdamW
+    mine, ref = make_params(0), make_params(0)
+    opt = FlatAdamW([(mine[:4], 2e-3), (mine[4:], 1e-3)], weight_decay=1e-2, max_norm=max_norm)
+    topt = torch.optim.AdamW([dict(params=ref[:4], lr=2e-3), dict(params=ref[4:], lr=1e-3)], lr=2e-3, weight_decay=1e-2)
+    assert all(p.data_ptr() >= opt.flat_p.data_ptr() for p in mine)
+    assert all(p.data_ptr() % 256 == 0 and p.grad.data_ptr() % 256 == 0 for p in mine)
+    assert all(torch.equal(a, b) for a, b in zip(mine, ref))  # flattening keeps the values
+    g = torch.Generator().manual_seed(1)
+    for step in range(5):
+        grads = [torch.randn(p.shape, generator=g).cuda() * (1 + step) for p in ref]
+        for p, q, gr in zip(mine, ref, grads):
+            p.grad.copy_(gr)
+            q.grad = gr.clone()
+        expect_norm = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(gr) for gr in grads]))
+        if max_norm is not None:
+            torch.nn.utils.clip_grad_norm_(ref, max_norm)
+        topt.step()
+        opt.step(zero_grad=True)
+        assert abs(float(opt.grad_norm) - float(expect_norm)) <= 1e-5 * float(expect_norm)
+        assert int(opt.step_count) == step + 1
+        for p, q in zip(mine, ref):
+            assert float((p - q).abs().max()) <= 2e-6 * max(1.0, float(q.abs().max())), step
+        assert float(opt.grads.flat.abs().max()) == 0.0  # cleared for the next step
+
+
+def test_flat_adamw_rejects_bad_input():
+    from hipad_amd import lib
+    from hipad_amd.optim import FlatAdamW
+    with pytest.raises(ValueError):
+        FlatAdamW([], max_norm=1.0)
+    p = [torch.nn.Parameter(torch.randn(8, 8).cuda())]
+    opt = FlatAdamW([(p, 1e-3)])
+    with pytest.raises(lib.HipadError):
+        lib.adamw_step(opt.flat_p, opt.grads.flat[:-4], opt.exp_avg, opt.exp_avg_sq, 0, 1e-3, 1e-3, (0.9, 0.999), 1e-8, 0.0,
+                       None, opt.step_count, None, opt._ws)

@@ -13,7 +13,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 img, data = frames.next()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
-    step.opt.zero_grad(set_to_none=True)
+    step.grads.zero()
     with record_function("ENCODER_FWD"):
         fm, depths = model.extract_feat(img, True, data)
     with record_function("DECODER_FWD"):
@@ -24,8 +24,7 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     with record_function("BACKWARD"):
         loss.backward()
     with record_function("OPT"):
-        torch.nn.utils.clip_grad_norm_(step.params, step.max_norm, foreach=True)
-        step.opt.step()
+        step.update()
     torch.cuda.synchronize()
 ka = prof.key_averages()
 rows = sorted(ka, key=lambda e: -e.count)
