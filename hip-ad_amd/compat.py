@@ -26,6 +26,17 @@ try:  # prefer the real thing when present (drop-in under the reference's tools/
 except Exception:  # noqa: BLE001 - any import problem means "not available"
     HAVE_MMCV = False
 
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm (same parameters / state_dict) on the HIP kernel for CUDA fp32 inputs: one forward and ONE
+    backward launch, gamma / beta gradients accumulated in place (hipad_amd.functional.layer_norm)."""
+
+    def forward(self, x):
+        from . import functional as HF
+        if x.is_cuda and len(self.normalized_shape) == 1 and self.weight is not None:
+            return HF.layer_norm(x, self.weight, self.bias, self.eps)
+        return super().forward(x)
+
+
 if not HAVE_MMCV:
 
     class Registry:
@@ -89,7 +100,7 @@ if not HAVE_MMCV:
     BACKBONES = _registry("backbone")
     NECKS = _registry("neck")
 
-    NORM_LAYERS.register_module("LN", module=nn.LayerNorm)
+    NORM_LAYERS.register_module("LN", module=LayerNorm)
 
     def build_from_cfg(cfg, registry, default_args=None):
         """Instantiate ``cfg['type']`` (a registered name or a class) with the remaining keys."""
@@ -203,7 +214,7 @@ def build_norm_layer(cfg, num_features, postfix=""):
     args = dict(cfg)
     kind = args.pop("type")
     if kind == "LN":
-        return f"ln{postfix}", nn.LayerNorm(num_features, **args)
+        return f"ln{postfix}", LayerNorm(num_features, **args)
     if kind == "BN":
         args.pop("requires_grad", None)
         return f"bn{postfix}", nn.BatchNorm2d(num_features, **args)

@@ -214,3 +214,52 @@ def linear(x, weight, bias=None, relu=False, rows=None):
         y = torch.nn.functional.linear(x, weight[r0:r1], None if bias is None else bias[r0:r1])
         return torch.relu(y) if relu else y
     return _Linear.apply(x, weight, bias, bool(relu), int(r0), int(r1))
+
+
+class _LayerNorm(Function):
+    """LayerNorm over the last dim; gamma / beta gradients are accumulated IN PLACE into ``weight.grad`` /
+    ``bias.grad`` when those exist (as _Linear does), so autograd has nothing to add for them."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        shape = x.shape
+        x2 = _c32(x.reshape(-1, shape[-1]))
+        need = any(ctx.needs_input_grad[:3])
+        y, mean, rstd = _lib.layernorm_forward(x2, None if weight is None else weight.detach(),
+                                               None if bias is None else bias.detach(), eps, need_stats=need)
+        if need:
+            ctx.save_for_backward(x2, mean, rstd)
+        ctx.weight, ctx.bias, ctx.in_shape = weight, bias, shape
+        return y.view(shape)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2, mean, rstd = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
+        dy2 = _c32(dy.reshape(x2.shape))
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        ret_w = ret_b = dgamma = dbeta = None
+        if weight is not None and ctx.needs_input_grad[1]:
+            g = weight.grad if LINEAR_INPLACE_GRAD else None
+            if g is not None and g.is_contiguous() and g.dtype == torch.float32:
+                dgamma = g
+            else:
+                dgamma = ret_w = torch.zeros_like(weight)
+        if bias is not None and ctx.needs_input_grad[2]:
+            g = bias.grad if LINEAR_INPLACE_GRAD else None
+            if g is not None and g.is_contiguous() and g.dtype == torch.float32:
+                dbeta = g
+            else:
+                dbeta = ret_b = torch.zeros_like(bias)
+        _lib.layernorm_backward(dy2, x2, mean, rstd, None if weight is None else weight.detach(), dx, dgamma, dbeta)
+        return (dx.view(ctx.in_shape) if dx is not None else None), ret_w, ret_b, None
+
+
+def layer_norm(x, weight, bias, eps=1e-5):
+    """LayerNorm over the last dimension on the HIP kernel (see include/hipad.h); CPU tensors (host-logic
+    tests) and shapes off the kernel's range go through torch."""
+    n = x.shape[-1]
+    if not x.is_cuda or n % 4 or n > 1024 or x.dtype != torch.float32:
+        return torch.nn.functional.layer_norm(x, (n,), weight, bias, eps)
+    return _LayerNorm.apply(x, weight, bias, float(eps))

@@ -29,6 +29,8 @@ SIGNATURES = {
     "hipad_weights_softmax_backward": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p]),
     "hipad_linear_forward": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "hipad_linear_backward": (c_int, [c_void_p] * 7 + [c_int] * 3 + [c_void_p]),
+    "hipad_layernorm_forward": (c_int, [c_void_p] * 6 + [c_int, c_int, ctypes.c_float, c_void_p]),
+    "hipad_layernorm_backward": (c_int, [c_void_p] * 8 + [c_int, c_int, c_void_p]),
     "hipad_adamw_workspace": (c_size_t, []),
     "hipad_adamw_step": (c_int, [c_void_p] * 4 + [ctypes.c_longlong] * 2 + [ctypes.c_float] * 7
                          + [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
@@ -321,3 +323,29 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, n_group0, lr0, lr1, betas, eps,
                                   _ptr(norm_out), workspace.data_ptr(), workspace.numel() * workspace.element_size(),
                                   int(bool(zero_grad)), stream_ptr(param.device))
     check(st, "hipad_adamw_step")
+
+
+def layernorm_forward(x2, gamma, beta, eps, need_stats=True):
+    """x2 (M,N) fp32 contiguous -> y, mean, rstd."""
+    lib = load()
+    _req(x2, torch.float32, "x")
+    M, N = x2.shape
+    y = torch.empty_like(x2)
+    mean = torch.empty(M, dtype=torch.float32, device=x2.device) if need_stats else None
+    rstd = torch.empty(M, dtype=torch.float32, device=x2.device) if need_stats else None
+    with torch.cuda.device(x2.device):
+        st = lib.hipad_layernorm_forward(y.data_ptr(), _ptr(mean), _ptr(rstd), x2.data_ptr(), _ptr(gamma), _ptr(beta), M, N,
+                                         float(eps), stream_ptr(x2.device))
+    check(st, "hipad_layernorm_forward")
+    return y, mean, rstd
+
+
+def layernorm_backward(dy2, x2, mean, rstd, gamma, dx, dgamma, dbeta):
+    """dx overwritten (or None); dgamma / dbeta accumulated into (or None)."""
+    lib = load()
+    _req(dy2, torch.float32, "dy")
+    M, N = x2.shape
+    with torch.cuda.device(x2.device):
+        st = lib.hipad_layernorm_backward(_ptr(dx), _ptr(dgamma), _ptr(dbeta), dy2.data_ptr(), x2.data_ptr(), mean.data_ptr(),
+                                          rstd.data_ptr(), _ptr(gamma), M, N, stream_ptr(x2.device))
+    check(st, "hipad_layernorm_backward")

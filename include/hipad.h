@@ -202,6 +202,23 @@ int hipad_linear_backward(float *dx, float *dw, float *db, const float *dy, cons
                           const float *x, const float *weight, int M, int N, int K, hipad_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * LayerNorm over the last dimension (hip-ad_amd/csrc/layernorm.hip).
+ * Replaces: nn.LayerNorm in the decoder -- linear_relu_ln stacks (reference models/blocks.py:32-42), the
+ *           "norm" ops of the decoder program (projects/configs/hipad_b2d_stage2.py:293), AsymmetricFFN's
+ *           pre-norm (blocks.py:352-353).
+ *   forward : y[M,N] = (x - mean) * rstd * gamma + beta ; mean / rstd [M] are written for the backward
+ *             (either may be NULL); gamma / beta may be NULL (= 1 / 0).  N % 4 == 0, N <= 1024.
+ *   backward: dx[M,N] overwritten (may be NULL); dgamma[N] / dbeta[N] ACCUMULATED with fp32 atomics (pass
+ *             the parameters' gradient buffers; either may be NULL).
+ * fp32, rstd = 1/sqrt(biased variance + eps): torch.nn.functional.layer_norm's arithmetic.
+ * ---------------------------------------------------------------------------------- */
+int hipad_layernorm_forward(float *y, float *mean, float *rstd, const float *x, const float *gamma,
+                            const float *beta, int M, int N, float eps, hipad_stream_t stream);
+int hipad_layernorm_backward(float *dx, float *dgamma, float *dbeta, const float *dy, const float *x,
+                             const float *mean, const float *rstd, const float *gamma, int M, int N,
+                             hipad_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Gradient clipping + AdamW over flat buffers (hip-ad_amd/csrc/optim.hip).
  * Replaces: the per-tensor optimiser step of the reference's training loop: mmcv OptimizerHook
  *           grad_clip (max_norm 25) + torch.optim.AdamW with the backbone at lr x0.5

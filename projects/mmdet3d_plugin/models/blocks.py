@@ -20,7 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from hipad_amd import functional as HF
-from hipad_amd.compat import (ATTENTION, FEEDFORWARD_NETWORK, PLUGIN_LAYERS, BaseModule, FusedReLU, Linear, Sequential,
+from hipad_amd.compat import (ATTENTION, FEEDFORWARD_NETWORK, PLUGIN_LAYERS, BaseModule, FusedReLU, LayerNorm, Linear, Sequential,
                               linear_relu,
                               build_activation_layer, build_dropout, build_from_cfg, build_norm_layer,
                               constant_init, xavier_init)
@@ -38,7 +38,7 @@ def linear_relu_ln(embed_dims, in_loops, out_loops, input_dims=None):
         for _ in range(in_loops):
             stack += list(linear_relu(width_in, embed_dims))  # ReLU fused into the GEMM epilogue
             width_in = embed_dims
-        stack.append(nn.LayerNorm(embed_dims))
+        stack.append(LayerNorm(embed_dims))
     return stack
 
 
