@@ -32,12 +32,20 @@ def _build_attns(attn, count):
     raise NotImplementedError(type(attn))
 
 
-def _take(tensor, spans):
-    """Concatenate token ranges [(start, end), ...] along dim 1 (a view when there is one range)."""
+def _pieces(tensor, cumsum):
+    """Per-modality views of a (bs, tokens, C) tensor.  ONE split instead of a slice per use: its backward
+    is a single concatenation of the piece gradients (a slice's backward is a zero-filled full-size tensor
+    plus a copy, per slice, plus the adds that merge them)."""
     if tensor is None:
         return None
-    parts = [tensor[:, s:e] for s, e in spans]
-    return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+    sizes = [int(cumsum[i + 1]) - int(cumsum[i]) for i in range(len(cumsum) - 1)]
+    return list(torch.split(tensor, sizes, dim=1))
+
+
+def _gather(pieces, idx):
+    if pieces is None:
+        return None
+    return pieces[idx[0]] if len(idx) == 1 else torch.cat([pieces[i] for i in idx], dim=1)
 
 
 class _GroupedAttention(nn.Module):
@@ -51,27 +59,35 @@ class _GroupedAttention(nn.Module):
         self._qgroups, self._kgroups = query_groups, key_groups
         self.attns = _build_attns(attn, len(query_groups))
 
-    def _spans(self, names, cumsum):
-        idx = [self.query_select.index(n) for n in names]
-        return [(int(cumsum[i]), int(cumsum[i + 1])) for i in idx]
+    def _indices(self, names):
+        return [self.query_select.index(n) for n in names]
 
     def _route(self, query, key, value, query_pos, key_pos, q_cumsum, k_cumsum, fc_before, fc_after,
                read_updated=False, attn_mask=None):
         if attn_mask is not None:
             raise NotImplementedError("attention masks are not used by the HiP-AD configs")
-        result = query.clone()
         self_attend = key is None
+        q_parts, qpos_parts = _pieces(query, q_cumsum), _pieces(query_pos, q_cumsum)
+        same_kv = (not self_attend) and value is key
+        k_parts = None if self_attend else (q_parts if key is query else _pieces(key, k_cumsum))
+        kpos_parts = None if self_attend else (qpos_parts if key_pos is query_pos else _pieces(key_pos, k_cumsum))
+        if value is None:
+            v_parts = None
+        elif self_attend:
+            v_parts = q_parts if value is query else _pieces(value, q_cumsum)
+        else:
+            v_parts = k_parts if same_kv else _pieces(value, k_cumsum)
+        out_parts = list(q_parts)  # modality slots that no group writes keep the input tokens
         for g, attn in enumerate(self.attns):
-            qs = self._spans(self._qgroups[g], q_cumsum)
-            q = _take(result if read_updated else query, qs)
-            qpos = _take(query_pos, qs)
+            qi = self._indices(self._qgroups[g])
+            q = _gather(out_parts if read_updated else q_parts, qi)
+            qpos = _gather(qpos_parts, qi)
             if self_attend:
-                k = v_in = kpos = None
-                vs = qs
-                v_in = _take(value, vs)
+                k = kpos = None
+                v_in = _gather(v_parts, qi)
             else:
-                ks = self._spans(self._kgroups[g], k_cumsum)
-                k, kpos, v_in = _take(key, ks), _take(key_pos, ks), _take(value, ks)
+                ki = self._indices(self._kgroups[g])
+                k, kpos, v_in = _gather(k_parts, ki), _gather(kpos_parts, ki), _gather(v_parts, ki)
                 if k.shape[1] == 0:  # nothing cached for these modalities: attend within the queries
                     k = kpos = None
                 if v_in is not None and v_in.shape[1] == 0:
@@ -86,11 +102,12 @@ class _GroupedAttention(nn.Module):
                 out = fc_after(attn(query=q, key=k, value=v_in, query_pos=qpos, key_pos=kpos))
             else:
                 out = attn(query=q, key=k, value=v_in, query_pos=qpos, key_pos=kpos)
-            off = 0
-            for s, e in qs:
-                result[:, s:e] = out[:, off:off + (e - s)]
-                off += e - s
-        return result
+            if len(qi) == 1:
+                out_parts[qi[0]] = out
+            else:
+                for i, piece in zip(qi, torch.split(out, [q_parts[i].shape[1] for i in qi], dim=1)):
+                    out_parts[i] = piece
+        return torch.cat(out_parts, dim=1)
 
 
 @ATTENTION.register_module()

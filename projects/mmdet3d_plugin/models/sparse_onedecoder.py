@@ -312,12 +312,16 @@ class SparseOneDecoder(BaseModule):
                     temp_tokens = torch.cat([b.temp_feature for b in cached], dim=1)
                     temp_embeds = torch.cat([b.temp_embed for b in cached], dim=1)
             elif op == "split":
-                for n, s, e in zip(order, self.num_anchor_cumsum[:-1], self.num_anchor_cumsum[1:]):
-                    br[n].feature, br[n].embed = tokens[:, s:e], embeds[:, s:e]
+                # one split per tensor (backward = one concatenation), not a slice per modality
+                sizes = [int(v) for v in self.num_anchor_list]
+                for n, f, e in zip(order, torch.split(tokens, sizes, dim=1), torch.split(embeds, sizes, dim=1)):
+                    br[n].feature, br[n].embed = f, e
                 if with_temp:
-                    for n, s, e in zip(order, self.num_temp_anchor_cumsum[:-1], self.num_temp_anchor_cumsum[1:]):
-                        if e > s or br[n].temp_feature is not None:
-                            br[n].temp_feature, br[n].temp_embed = temp_tokens[:, s:e], temp_embeds[:, s:e]
+                    tsizes = [int(v) for v in self.num_temp_anchor_list]
+                    for n, c, f, e in zip(order, tsizes, torch.split(temp_tokens, tsizes, dim=1),
+                                          torch.split(temp_embeds, tsizes, dim=1)):
+                        if c > 0 or br[n].temp_feature is not None:
+                            br[n].temp_feature, br[n].temp_embed = f, e
             elif op == "temp_gnn":
                 tokens = layer(tokens, temp_tokens, temp_tokens, query_pos=embeds, key_pos=temp_embeds,
                                num_anchor_cumsum=self.num_anchor_cumsum,

@@ -7,6 +7,10 @@ import torch
 from hipad_amd.frame import build_detector, SyntheticFrames, GraphedTrainStep
 plan = int(sys.argv[1]) if len(sys.argv) > 1 else 480
 bs = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+if os.environ.get("BENCH") == "1":
+    torch.backends.cudnn.benchmark = True
+if os.environ.get("IMM") == "1":
+    torch.backends.miopen.immediate = True
 if os.environ.get("SEED1234"):
     torch.manual_seed(1234)
 model, cfg = build_detector(stage=2, plan_queries=plan)
