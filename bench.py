@@ -237,6 +237,32 @@ class Stage2Full:
         return {k: round(v, 3) for k, v in acc.items()}
 
 
+def _daf_grid_threads(A, P, cams=6, bs=1):
+    """Threads of the wave-per-item aggregation launches for (A, P): the host-side work split of
+    hip-ad_amd/csrc/daf.hip make_plan(), restated to find this launch in the rocprofv3 counter files."""
+    n_anchor = bs * A
+    want_chunks = (4096 + n_anchor - 1) // n_anchor
+    target = max(24, ((P + want_chunks - 1) // want_chunks) * cams)
+    target = min(target, 128)
+    ppc = min(P, max(1, target // cams))
+    nchunks = (P + ppc - 1) // ppc
+    ppc = (P + nchunks - 1) // nchunks
+    nchunks = (P + ppc - 1) // ppc
+    return ((n_anchor * nchunks + 3) // 4) * 256
+
+
+def pmc_traffic(kernel, A, P):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE,
+    tools/pmc_traffic.py; MI355X_MICROARCH.md HBM section), or None when the file has no such launch."""
+    path = os.path.join(ROOT, "profiles", "r01f_daf_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        table = json.load(f)["kernels"]
+    hit = table.get("hipad::%s grid=%d" % (kernel, _daf_grid_threads(A, P)))
+    return None if hit is None else hit["hbm_bytes_per_launch"]
+
+
 def roofline_of(daf):
     kt = daf.kernel_times()
     single = {k: v for k, v in kt.items() if k[1] in ("fwd", "bwd_lw")}  # single-kernel launches
@@ -244,10 +270,13 @@ def roofline_of(daf):
     dcall = next(d for d in daf.calls if d["name"] == dom[0])
     alg = daf.alg_bytes(dcall, dom[1])
     achieved = alg / (kt[dom] * 1e-3) / 1e9
-    kname = {"fwd": "daf_fwd_c256_kernel<4>", "bwd_lw": "daf_bwd_lw_kernel<4,true>"}[dom[1]]
+    kname = {"fwd": "daf_fwd_c256_kernel<4>", "bwd_lw": "daf_bwd_lw_kernel<4, true>"}[dom[1]]
     return dict(bound="hbm", kernel=f"{kname} [{dom[0]}: A={dcall['A']} P={dcall['P']}]",
                 achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                traffic=None, alg_bytes_per_launch=alg, avg_launch_ms=round(kt[dom], 4),
+                traffic=pmc_traffic(kname, dcall["A"], dcall["P"]),
+                traffic_source="profiles/r01f_daf_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                               "`bench.py --workload daf_stage2`, bytes per launch)",
+                alg_bytes_per_launch=alg, avg_launch_ms=round(kt[dom], 4),
                 all_kernels_ms={f"{k[0]}_{k[1]}": round(v, 4) for k, v in kt.items()})
 
 
