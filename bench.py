@@ -11,10 +11,9 @@ Workloads
   stage2_full  (default) one TRAINING step of the whole hipad_b2d_stage2 model on one frame per GPU:
                ResNet50 + FPN (bf16, channels-last) -> flat pyramid -> unified decoder (det 900 + map 100 +
                plan 480 + ego 1 queries, 6 layers, motion head; hand-written aggregation / projection /
-               softmax-weight / attention kernels, bf16 GEMMs) -> objective -> backward -> gradient
-               all-reduce (RCCL) -> clip -> AdamW.  The objective is a surrogate over every head output
-               (the reference's loss/target-assignment path is a "next" row) -- said in
-               config.workload.  --plan-queries 48 gives BASELINE.json's 6x8 wording.
+               softmax-weight / attention kernels, bf16 GEMMs) -> the reference's losses with the Hungarian
+               target assignment on the device (criterion.py, hipad_linear_assignment) -> backward -> gradient
+               all-reduce (RCCL) -> clip -> AdamW.  --plan-queries 48 gives BASELINE.json's 6x8 wording.
   daf_stage2   the aggregation path of one stage-2 frame: for each of the 6 decoder layers the
                four deformable-aggregation calls (det 900x13, map 100x300, plan 480x90, ego 1x13
                key points; 6 cams x 4 levels x 8 groups; C=256 fp32) forward AND backward on the
@@ -207,24 +206,31 @@ class Stage2Full:
         loss, gn = float(self.last_loss), float(self.train_step.grad_norm)
         return dict(loss=round(loss, 4), grad_norm_before_clip=round(gn, 3), finite=bool(np.isfinite(loss) and np.isfinite(gn)))
 
+    def loss_terms(self):
+        """Every loss term of one extra eager frame (names and values, for the record in the JSON line)."""
+        from hipad_amd.frame import frame_losses
+        with torch.no_grad():
+            img, data = self.frames.next()
+            was = self.model.head.onedecoder_head.run_step
+            losses = frame_losses(self.model, img, data)
+            self.model.head.onedecoder_head.run_step = was
+        return {k: round(float(v), 4) for k, v in losses.items()}
+
     def breakdown(self, reps=5):
         """ms per frame of the encoder forward, decoder forward and the rest, by HIP events, launched
         EAGERLY (so it includes launch gaps the graph replay does not have; shares, not the headline)."""
-        from hipad_amd.frame import DECODER_DTYPE, surrogate_objective
+        from hipad_amd.frame import _frame_loss
         if self.model.use_grid_mask:
             self.model.grid_mask.external_randomize = False
         ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
-        acc = dict(encoder_fwd=0.0, decoder_fwd=0.0, backward_opt=0.0)
+        acc = dict(encoder_fwd=0.0, decoder_fwd=0.0, backward_opt=0.0)  # encoder_fwd is folded into decoder_fwd
         for _ in range(reps):
             img, data = self.frames.next()
             self.train_step.grads.zero()
             e = [ev() for _ in range(4)]
             e[0].record()
-            fm, depths = self.model.extract_feat(img, True, data)
             e[1].record()
-            with torch.autocast("cuda", dtype=DECODER_DTYPE, enabled=DECODER_DTYPE != torch.float32):
-                outs = self.model.head(img, fm, data)
-            loss = surrogate_objective(outs, depths)
+            loss = _frame_loss(self.model, img, data)
             e[2].record()
             loss.backward()
             self.train_step.grads.check_views()
@@ -309,16 +315,16 @@ def main():
     daf = wl.daf if full else wl
     roof = roofline_of(daf)
     if full:
-        workload = ("stage2_full: one training step (fwd + surrogate objective over every head + bwd + grad all-reduce "
-                    "+ clip + AdamW) of hipad_b2d_stage2 on one 6-cam 704x256 frame per GPU: ResNet50+FPN bf16 "
-                    f"channels-last, decoder det 900 + map 100 + plan {a.plan_queries} + ego 1 queries x 6 layers + motion "
-                    "head, bf16 GEMMs / bf16-operand attention, fp32 aggregation; surrogate objective: the reference's "
-                    "loss + Hungarian assignment are not built yet (SURVEY 8f row 1)")
+        workload = ("stage2_full: one training step (forward + the reference's losses with device-side Hungarian target "
+                    "assignment [det/map/motion/ego/plan/depth terms] + backward + grad all-reduce + clip + AdamW) of "
+                    "hipad_b2d_stage2 on one 6-cam 704x256 frame per GPU: ResNet50+FPN bf16 channels-last, decoder det 900 "
+                    f"+ map 100 + plan {a.plan_queries} + ego 1 queries x 6 layers + motion head, bf16 GEMMs / bf16-operand "
+                    "attention, fp32 aggregation; synthetic ground truth (~20 boxes, ~10 map lines per frame)")
         dtype = "bf16"
         cfg = dict(workload=workload, frames_per_gpu_per_step=a.bs, plan_queries=a.plan_queries, parallelism=f"dp{world}",
                    launch="eager" if a.eager else "hipGraph replay (fwd+bwd graph, eager RCCL all-reduce, clip+AdamW graph)",
                    eager_frame_breakdown_ms=wl.breakdown() if (rank == 0 and a.eager) else None,
-                   last_step=sanity,
+                   last_step=sanity, loss_terms=wl.loss_terms() if rank == 0 else None,
                    roofline_scope="dominant hand-written kernel (deformable aggregation); encoder convolutions and "
                                   "GEMMs are MIOpen / hipBLASLt library calls")
     else:

@@ -244,6 +244,10 @@ def reduce_mean(tensor):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return tensor
+    if tensor.is_cuda and torch.cuda.is_current_stream_capturing():
+        # inside a captured step the positive counts stay per rank (no collective in the graph); the only
+        # exchange of a replayed step is the flat-gradient all-reduce between the two graphs
+        return tensor
     tensor = tensor.clone()
     dist.all_reduce(tensor.div_(dist.get_world_size()), op=dist.ReduceOp.SUM)
     return tensor

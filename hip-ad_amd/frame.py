@@ -41,6 +41,8 @@ def build_detector(stage=2, input_hw=(256, 704), plan_queries=None, device="cuda
 class SyntheticFrames:
     """Endless stream of synthetic frames with consistent ego motion (SURVEY.md section 8d inputs)."""
 
+    MAX_DET, MAX_MAP = 32, 16  # capacity of the padded ground-truth tensors
+
     def __init__(self, bs=1, input_hw=(256, 704), device="cuda", seed=0):
         self.bs, self.hw, self.device = bs, input_hw, device
         self.gen = torch.Generator(device="cpu").manual_seed(seed)
@@ -54,6 +56,15 @@ class SyntheticFrames:
         cmd[:, 3] = 1
         self.cmd = cmd.to(device)
         self.target = (torch.rand(bs, 2, generator=self.gen) * 60 - 30).to(device)
+        # ground truth for the loss path: a small pool of pre-generated, padded sets resident in HBM
+        from projects.mmdet3d_plugin.models.criterion import pad_ground_truth
+        self.gt_pool = []
+        for k in range(4):
+            raw = syn.ground_truth(bs=bs, seed=seed * 16 + k, input_hw=input_hw)
+            raw = {key: ([t.to(device) for t in v] if isinstance(v, list) else v.to(device)) for key, v in raw.items()}
+            dense = {key: v for key, v in raw.items() if not key.startswith(("gt_bboxes", "gt_labels", "gt_agent", "gt_map"))}
+            dense["gt_padded"] = pad_ground_truth(raw, max_det=self.MAX_DET, max_map=self.MAX_MAP)
+            self.gt_pool.append(dense)
 
     def next(self):
         k = self.step
@@ -63,6 +74,7 @@ class SyntheticFrames:
                     timestamp=torch.full((self.bs,), 0.5 * k, dtype=torch.float64, device=self.device),
                     img_metas=[dict(T_global=T, T_global_inv=Tinv) for _ in range(self.bs)],
                     gt_ego_fut_cmd=self.cmd, target_point=self.target)
+        data.update(self.gt_pool[k % len(self.gt_pool)])
         self.step += 1
         return self.pool[k % len(self.pool)], data
 
@@ -167,6 +179,11 @@ class GraphedTrainStep:
         self.data = dict(projection_mat=data["projection_mat"], image_wh=data["image_wh"], timestamp=self.ts,
                          T_temp2cur=self.T, img_metas=data["img_metas"], gt_ego_fut_cmd=data["gt_ego_fut_cmd"],
                          target_point=data["target_point"])
+        # ground truth of the loss path: static buffers refreshed by _feed (a handful of small device copies)
+        self._gt_keys = [k for k in data if k == "gt_padded" or k == "gt_depth" or k.startswith("ego_status")
+                         or (k.startswith("gt_ego_") and k != "gt_ego_fut_cmd")]
+        for k in self._gt_keys:
+            self.data[k] = _clone_tree(data[k])
         self._prev_T = None
         self._feed(img, data)
         # cold frames (no temporal cache yet) run eagerly; they also size every workspace / cache
@@ -218,6 +235,8 @@ class GraphedTrainStep:
         self.T.copy_(T_host, non_blocking=True)
         self.ts.copy_(ts_host, non_blocking=True)
         done.record()
+        for k in self._gt_keys:
+            _copy_tree(self.data[k], data[k])
         if self.model.use_grid_mask and getattr(self.model.grid_mask, "_last_h", None) is not None:
             self.model.grid_mask.randomize(self.img.device)
 
@@ -250,11 +269,52 @@ class GraphedTrainStep:
         return self.loss
 
 
+def _clone_tree(obj):
+    if isinstance(obj, torch.Tensor):
+        return obj.clone()
+    if isinstance(obj, dict):
+        return {k: _clone_tree(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [_clone_tree(v) for v in obj]
+    return obj
+
+
+def _copy_tree(dst, src):
+    if isinstance(dst, torch.Tensor):
+        dst.copy_(src, non_blocking=True)
+    elif isinstance(dst, dict):
+        for k in dst:
+            _copy_tree(dst[k], src[k])
+    elif isinstance(dst, list):
+        for d, s_ in zip(dst, src):
+            _copy_tree(d, s_)
+
+
 DECODER_DTYPE = torch.float32  # no autocast in the decoder: its Linear layers are the bf16-operand MFMA kernel
 
 
-def _frame_loss(det, img, data):
+def frame_losses(det, img, data):
+    """The reference's forward_train (models/sparse_detector.py:141-151): encoder, decoder, the decoder's losses
+    (target assignment included) and the dense-depth loss -> dict of scalar losses."""
     feature_maps, depths = det.extract_feat(img, True, data)
     with torch.autocast("cuda", dtype=DECODER_DTYPE, enabled=DECODER_DTYPE != torch.float32):
         outs = det.head(img, feature_maps, data)
-    return surrogate_objective(outs, depths)
+    losses = det.head.loss(outs, data)
+    if depths is not None and "gt_depth" in data:
+        losses["loss_dense_depth"] = det.depth_branch.loss(depths, data["gt_depth"])
+    return losses
+
+
+def _frame_loss(det, img, data):
+    if OBJECTIVE == "surrogate":
+        feature_maps, depths = det.extract_feat(img, True, data)
+        outs = det.head(img, feature_maps, data)
+        return surrogate_objective(outs, depths)
+    losses = frame_losses(det, img, data)
+    total = None
+    for v in losses.values():
+        total = v if total is None else total + v
+    return total
+
+
+OBJECTIVE = "losses"  # "surrogate": mean square of every head output (debugging aid; skips target assignment)

@@ -31,6 +31,7 @@ SIGNATURES = {
     "hipad_linear_backward": (c_int, [c_void_p] * 7 + [c_int] * 3 + [c_void_p]),
     "hipad_layernorm_forward": (c_int, [c_void_p] * 6 + [c_int, c_int, ctypes.c_float, c_void_p]),
     "hipad_layernorm_backward": (c_int, [c_void_p] * 8 + [c_int, c_int, c_void_p]),
+    "hipad_linear_assignment": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
     "hipad_adamw_workspace": (c_size_t, []),
     "hipad_adamw_step": (c_int, [c_void_p] * 4 + [ctypes.c_longlong] * 2 + [ctypes.c_float] * 7
                          + [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
@@ -349,3 +350,18 @@ def layernorm_backward(dy2, x2, mean, rstd, gamma, dx, dgamma, dbeta):
         st = lib.hipad_layernorm_backward(_ptr(dx), _ptr(dgamma), _ptr(dbeta), dy2.data_ptr(), x2.data_ptr(), mean.data_ptr(),
                                           rstd.data_ptr(), _ptr(gamma), M, N, stream_ptr(x2.device))
     check(st, "hipad_layernorm_backward")
+
+
+def linear_assignment(cost, n_rows):
+    """cost (B, R, C) fp32 (rows = ground truth, cols = predictions), n_rows (B,) int32 -> col_of_row (B, R) int32."""
+    lib = load()
+    _req(cost, torch.float32, "cost")
+    _req(n_rows, torch.int32, "n_rows")
+    B, R, C = cost.shape
+    if n_rows.numel() != B:
+        raise HipadError("linear_assignment: n_rows must have one entry per problem")
+    out = torch.empty(B, R, dtype=torch.int32, device=cost.device)
+    with torch.cuda.device(cost.device):
+        st = lib.hipad_linear_assignment(out.data_ptr(), cost.data_ptr(), n_rows.data_ptr(), B, R, C, stream_ptr(cost.device))
+    check(st, "hipad_linear_assignment")
+    return out

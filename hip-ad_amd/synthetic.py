@@ -179,3 +179,51 @@ def project(key_points, projection_mat, image_wh):
     p = np.einsum("bcij,bapj->bapci", projection_mat.astype(np.float32), kp.astype(np.float32))
     uv = p[..., :2] / np.maximum(p[..., 2:3], np.float32(1e-5))
     return (uv / image_wh[:, None, None]).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------
+# synthetic ground truth for the loss path (20 boxes / 10 poly-lines per sample)
+# ------------------------------------------------------------------------------------------
+def ground_truth(bs=1, seed=0, n_det=20, n_map=10, num_det_cls=9, num_map_cls=4, ts=6, num_pts=20,
+                 input_hw=(256, 704), depth_strides=(4, 8, 16), cams=6, sparse_depth=0.03):
+    """Ragged ground truth in the reference's data format (keys of the train pipeline's Collect,
+    projects/configs/hipad_b2d_stage2.py:516-523), as CPU torch tensors.  Box counts vary a little per
+    sample so the padded path is exercised."""
+    import torch
+    g = torch.Generator().manual_seed(1000 + seed)
+    r = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    u = lambda *s: torch.rand(*s, generator=g)  # noqa: E731
+    data = dict(gt_bboxes_3d=[], gt_labels_3d=[], gt_agent_fut_trajs=[], gt_agent_fut_masks=[], gt_map_pts=[],
+                gt_map_labels=[])
+    for b in range(bs):
+        n = max(1, n_det - (b + seed) % 4)
+        box = torch.cat([(u(n, 3) * 2 - 1) * torch.tensor([14.0, 28.0, 1.5]), u(n, 3) * 3.0 + 0.6,
+                         (u(n, 1) * 2 - 1) * math.pi, r(n, 2) * 3.0], dim=1)
+        data["gt_bboxes_3d"].append(box)
+        data["gt_labels_3d"].append(torch.randint(0, num_det_cls, (n,), generator=g))
+        data["gt_agent_fut_trajs"].append(r(n, ts, 2) * 0.8)
+        data["gt_agent_fut_masks"].append((u(n, ts) > 0.2).float())
+        m = max(1, n_map - (b + seed) % 3)
+        t = torch.linspace(0, 1, num_pts)[None, :, None]
+        a, c = (u(m, 1, 2) * 2 - 1) * torch.tensor([13.0, 27.0]), (u(m, 1, 2) * 2 - 1) * torch.tensor([13.0, 27.0])
+        line = a + (c - a) * t + r(m, num_pts, 2) * 0.2
+        perms = torch.full((m, 2 * (num_pts - 1), num_pts, 2), 1e5)  # VectorizePloyLine(permute=True) padding
+        perms[:, 0], perms[:, 1] = line, line.flip(1)
+        data["gt_map_pts"].append(perms)
+        data["gt_map_labels"].append(torch.randint(0, num_map_cls, (m,), generator=g))
+    data["ego_status"] = r(bs, 6)
+    data["ego_status_mask"] = torch.ones(bs, 6)
+    step = torch.cumsum(u(bs, ts, 1) * torch.tensor([0.1, 1.0]) + torch.tensor([0.0, 0.5]), dim=1)
+    for rate, scale in (("2hz", 1.0), ("5hz", 0.4)):
+        data[f"gt_ego_fut_trajs_{rate}"] = torch.diff(step * scale, dim=1, prepend=torch.zeros(bs, 1, 2))
+        data[f"gt_ego_fut_masks_{rate}"] = torch.ones(bs, ts)
+    for rate, scale in (("2m", 0.4), ("5m", 1.0)):
+        data[f"gt_ego_spat_trajs_{rate}"] = torch.diff(step * scale, dim=1, prepend=torch.zeros(bs, 1, 2))
+        data[f"gt_ego_spat_masks_{rate}"] = torch.ones(bs, ts)
+    depth = []
+    for s in depth_strides:
+        h, w = input_hw[0] // s, input_hw[1] // s
+        d = u(bs * cams, h, w) * 50.0 + 1.0
+        depth.append(torch.where(u(bs * cams, h, w) < sparse_depth, d, torch.zeros_like(d)))  # LiDAR-sparse
+    data["gt_depth"] = depth
+    return data

@@ -162,8 +162,12 @@ class DenseDepthNet(BaseModule):
             pred = pred.permute(0, 2, 3, 1).reshape(-1)
             gt = gt.reshape(-1)
             valid = (gt > 0.0) & ~torch.isnan(pred)
-            err = (pred[valid].clamp(0.0, self.max_depth).float() - gt[valid].float()).abs().sum()
-            total = total + err / max(1.0, float(valid.sum()) * len(depth_preds)) * self.loss_weight
+            # masked sum instead of the reference's boolean indexing (blocks.py:313-316): same value, no
+            # data-dependent shape and no host synchronisation (the step stays capturable)
+            diff = (pred.float().clamp(0.0, self.max_depth) - gt.float()).abs()
+            err = torch.where(valid, diff, torch.zeros_like(diff)).sum()
+            count = torch.clamp(valid.sum().float() * len(depth_preds), min=1.0)
+            total = total + err / count * self.loss_weight
         return total
 
 

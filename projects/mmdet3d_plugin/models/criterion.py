@@ -1,0 +1,566 @@
+"""Training objective of the unified decoder on the device, in static shapes.
+
+What it computes is the reference's ``SparseOneDecoder.loss`` (models/sparse_onedecoder.py:1094-1579) with its
+samplers (det/target.py:66-162, map/target.py:38-62 + 105-160, map/match_cost.py, motion/target.py:71-99,
+plan/target.py:80-162) and loss modules (det/losses.py:11-93, map/loss.py:10-120, plus mmdet==2.28.2's
+FocalLoss / L1Loss / CrossEntropyLoss / GaussianFocalLoss / FocalLossCost, a third-party package that is not
+installed here: their published formulas are restated below).
+
+How it differs underneath (same numbers):
+  * ground truth arrives PADDED -- ``(bs, G, ...)`` tensors plus a per-sample count -- instead of Python lists of
+    ragged tensors, so every tensor of the step has a static shape;
+  * the Hungarian matching runs on the device (``hipad_linear_assignment``), not through ``.cpu().numpy()`` +
+    SciPy: no host synchronisation, the whole step stays capturable in a hipGraph;
+  * the reference selects the matched rows with boolean-mask indexing (data-dependent shapes, a host sync per
+    use); every loss here is a masked sum over all rows -- the same value, because all of those losses are
+    sums divided by ``num_pos``.
+The registered classes keep the reference's names and constructor keywords so its configs build them.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from hipad_amd.compat import BBOX_SAMPLERS, LOSSES, build_from_cfg, reduce_mean
+from projects.mmdet3d_plugin.core.box3d import CNS, COS_YAW, SIN_YAW, YNS
+
+__all__ = ["FocalLoss", "L1Loss", "CrossEntropyLoss", "GaussianFocalLoss", "SparseBox3DLoss", "LinesL1Loss",
+           "SparseLineLoss", "SparseBox3DTarget", "SparsePoint3DTarget", "SparsePlanTarget", "AlignPlanTarget",
+           "SparseMotionTarget", "DecoderLoss", "pad_ground_truth", "linear_assignment"]
+
+_EPS = float(torch.finfo(torch.float32).eps)  # mmdet.models.losses.utils.weight_reduce_loss
+
+
+_CONSTS = {}
+
+
+def _const(values, like):
+    """Small constant vector on ``like``'s device, created once per (values, device, dtype): building it from a
+    Python list inside a captured step would be a pageable host->device copy, which a capture cannot hold."""
+    key = (tuple(float(v) for v in values), like.device, like.dtype)
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.tensor(key[0], dtype=like.dtype, device=like.device)
+    return t
+
+
+def _reduce(loss, weight=None, avg_factor=None):
+    """mmdet's weight_reduce_loss for reduction='mean': mean of the elements, or sum / (avg_factor + eps)."""
+    if weight is not None:
+        if weight.dim() == loss.dim() - 1:
+            weight = weight.unsqueeze(-1)
+        loss = loss * weight.to(loss.dtype)
+    return loss.mean() if avg_factor is None else loss.sum() / (avg_factor + _EPS)
+
+
+def linear_assignment(cost_gt_major, count):
+    """(bs, G, P) costs, (bs,) int32 valid-row counts -> (bs, G) int64 prediction index per ground-truth row
+    (-1 for padding).  Device kernel for CUDA tensors; SciPy for CPU tensors (host-logic tests only)."""
+    if cost_gt_major.is_cuda:
+        from hipad_amd import lib
+        return lib.linear_assignment(cost_gt_major.detach().float().contiguous(), count.to(torch.int32)).long()
+    from scipy.optimize import linear_sum_assignment
+    out = torch.full(cost_gt_major.shape[:2], -1, dtype=torch.long)
+    for b in range(cost_gt_major.shape[0]):
+        n = int(count[b])
+        if n:
+            rows, cols = linear_sum_assignment(cost_gt_major[b, :n].detach().double().numpy())
+            out[b, torch.as_tensor(rows)] = torch.as_tensor(cols)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# mmdet loss modules (restated formulas; reduction 'mean' only, which is all the configs use)
+# ------------------------------------------------------------------------------------------------
+@LOSSES.register_module()
+class FocalLoss(nn.Module):
+    """Sigmoid focal loss on logits (N, C) with integer targets in [0, C], C = background."""
+
+    def __init__(self, use_sigmoid=True, gamma=2.0, alpha=0.25, reduction="mean", loss_weight=1.0, activated=False):
+        super().__init__()
+        if not use_sigmoid or activated or reduction != "mean":
+            raise NotImplementedError("only the sigmoid / logits / mean variant used by the HiP-AD configs")
+        self.gamma, self.alpha, self.loss_weight = gamma, alpha, loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None):
+        c = pred.shape[-1]
+        t = F.one_hot(target, c + 1)[..., :c].to(pred.dtype)
+        p = pred.sigmoid()
+        pt = (1 - p) * t + p * (1 - t)
+        focal = (self.alpha * t + (1 - self.alpha) * (1 - t)) * pt.pow(self.gamma)
+        loss = F.binary_cross_entropy_with_logits(pred, t, reduction="none") * focal
+        return self.loss_weight * _reduce(loss, weight, avg_factor)
+
+
+@LOSSES.register_module()
+class L1Loss(nn.Module):
+    def __init__(self, reduction="mean", loss_weight=1.0):
+        super().__init__()
+        self.loss_weight = loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None):
+        return self.loss_weight * _reduce((pred - target).abs(), weight, avg_factor)
+
+
+@LOSSES.register_module()
+class CrossEntropyLoss(nn.Module):
+    """Binary cross entropy on logits against soft targets (the ``use_sigmoid=True`` form)."""
+
+    def __init__(self, use_sigmoid=False, reduction="mean", loss_weight=1.0, **kwargs):
+        super().__init__()
+        if not use_sigmoid:
+            raise NotImplementedError("only use_sigmoid=True is used by the HiP-AD configs")
+        self.loss_weight = loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None):
+        loss = F.binary_cross_entropy_with_logits(pred, target.to(pred.dtype), reduction="none")
+        return self.loss_weight * _reduce(loss, weight, avg_factor)
+
+
+@LOSSES.register_module()
+class GaussianFocalLoss(nn.Module):
+    def __init__(self, alpha=2.0, gamma=4.0, reduction="mean", loss_weight=1.0):
+        super().__init__()
+        self.alpha, self.gamma, self.loss_weight = alpha, gamma, loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None):
+        eps = 1e-12
+        pos = -(pred + eps).log() * (1 - pred).pow(self.alpha) * target.eq(1).to(pred.dtype)
+        neg = -(1 - pred + eps).log() * pred.pow(self.alpha) * (1 - target).pow(self.gamma)
+        return self.loss_weight * _reduce(pos + neg, weight, avg_factor)
+
+
+def _smooth_l1(diff_abs, beta):
+    if beta > 0:
+        return torch.where(diff_abs < beta, 0.5 * diff_abs * diff_abs / beta, diff_abs - 0.5 * beta)
+    return diff_abs
+
+
+@LOSSES.register_module()
+class LinesL1Loss(nn.Module):
+    def __init__(self, reduction="mean", loss_weight=1.0, beta=0.5):
+        super().__init__()
+        self.loss_weight, self.beta = loss_weight, beta
+
+    def forward(self, pred, target, weight=None, avg_factor=None):
+        loss = _reduce(_smooth_l1((pred - target).abs(), self.beta), weight, avg_factor)
+        return loss / (pred.shape[-1] // 2) * self.loss_weight
+
+
+def _normalize_line(line, num_sample, roi_size):
+    """(…, num_sample*2) metric poly-line -> roi-normalised (reference map/loss.py:108-120, map/target.py:64-76)."""
+    pts = line.reshape(line.shape[:-1] + (num_sample, -1))
+    origin = _const([-roi_size[0] / 2, -roi_size[1] / 2], pts)
+    norm = _const([roi_size[0] + 1e-5, roi_size[1] + 1e-5], pts)
+    return ((pts - origin) / norm).flatten(-2, -1)
+
+
+@LOSSES.register_module()
+class SparseLineLoss(nn.Module):
+    def __init__(self, loss_line, num_sample=20, roi_size=(30, 60)):
+        super().__init__()
+        self.loss_line = build_from_cfg(loss_line, LOSSES)
+        self.num_sample, self.roi_size = num_sample, roi_size
+
+    def forward(self, line, line_target, weight=None, avg_factor=None, prefix="", suffix="", **kwargs):
+        line = _normalize_line(line, self.num_sample, self.roi_size)
+        line_target = _normalize_line(line_target, self.num_sample, self.roi_size)
+        return {f"{prefix}loss_line{suffix}": self.loss_line(line, line_target, weight=weight, avg_factor=avg_factor)}
+
+
+@LOSSES.register_module()
+class SparseBox3DLoss(nn.Module):
+    """Box L1 + centerness + yawness.  ``row_mask`` (N,) marks the rows the reference would have kept with
+    boolean indexing; it multiplies every term instead."""
+
+    def __init__(self, loss_box, loss_centerness=None, loss_yawness=None, cls_allow_reverse=None):
+        super().__init__()
+        if cls_allow_reverse is not None:
+            raise NotImplementedError("cls_allow_reverse is unused by the HiP-AD configs")
+        self.loss_box = build_from_cfg(loss_box, LOSSES)
+        self.loss_cns = build_from_cfg(loss_centerness, LOSSES)
+        self.loss_yns = build_from_cfg(loss_yawness, LOSSES)
+
+    def forward(self, box, box_target, weight=None, avg_factor=None, prefix="", suffix="", quality=None,
+                cls_target=None, row_mask=None, **kwargs):
+        m = None if row_mask is None else row_mask.to(box.dtype)
+        w = weight if m is None else (m[:, None] if weight is None else weight * m[:, None])
+        out = {f"{prefix}loss_box{suffix}": self.loss_box(box, box_target, weight=w, avg_factor=avg_factor)}
+        if quality is not None:
+            cns, yns = quality[..., CNS], quality[..., YNS].sigmoid()
+            cns_target = torch.exp(-torch.norm(box_target[..., :3] - box[..., :3], p=2, dim=-1))
+            out[f"{prefix}loss_cns{suffix}"] = self.loss_cns(cns, cns_target, weight=m, avg_factor=avg_factor)
+            yaw = slice(SIN_YAW, COS_YAW + 1)  # a slice, not an index list: list indices are uploaded at run time
+            yns_target = (F.cosine_similarity(box_target[..., yaw], box[..., yaw], dim=-1) > 0).to(box.dtype)
+            out[f"{prefix}loss_yns{suffix}"] = self.loss_yns(yns, yns_target, weight=m, avg_factor=avg_factor)
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+# target assignment
+# ------------------------------------------------------------------------------------------------
+def _focal_cost(logits, labels, alpha=0.25, gamma=2.0, eps=1e-12):
+    """(bs, P, C) logits, (bs, G) labels -> (bs, P, G): mmdet FocalLossCost / det/target.py:126-149."""
+    p = logits.sigmoid()
+    neg = -(1 - p + eps).log() * (1 - alpha) * p.pow(gamma)
+    pos = -(p + eps).log() * alpha * (1 - p).pow(gamma)
+    idx = labels.clamp(min=0)[:, None, :].expand(-1, logits.shape[1], -1)
+    return torch.gather(pos - neg, 2, idx)
+
+
+def _scatter_rows(num_pred, index, value, fill=0.0):
+    """out[b, index[b, g]] = value[b, g] for index >= 0 (rows with index < 0 are dropped); out (bs, num_pred, …)."""
+    bs = index.shape[0]
+    slot = torch.where(index >= 0, index, torch.full_like(index, num_pred))  # dropped rows land in a spare slot
+    out = value.new_full((bs, num_pred + 1) + value.shape[2:], fill)
+    view = slot.reshape(slot.shape + (1,) * (value.dim() - 2)).expand_as(value)
+    out.scatter_(1, view, value)
+    return out[:, :num_pred]
+
+
+@BBOX_SAMPLERS.register_module()
+class SparseBox3DTarget:
+    def __init__(self, cls_weight=2.0, alpha=0.25, gamma=2, eps=1e-12, box_weight=0.25, reg_weights=None,
+                 cls_wise_reg_weights=None, num_dn_groups=0, dn_noise_scale=0.5, max_dn_gt=32, add_neg_dn=True,
+                 num_temp_dn_groups=0):
+        if num_dn_groups or num_temp_dn_groups:
+            raise NotImplementedError("denoising queries are off in the HiP-AD configs")
+        self.cls_weight, self.box_weight, self.alpha, self.gamma, self.eps = cls_weight, box_weight, alpha, gamma, eps
+        self.reg_weights = reg_weights if reg_weights is not None else [1.0] * 8 + [0.0] * 2
+        self.cls_wise_reg_weights = cls_wise_reg_weights
+        self.dn_metas = None
+        self.indices = None
+
+    @staticmethod
+    def encode_reg_target(boxes):
+        """decoded (…, [x,y,z,w,l,h,yaw,v…]) -> (…, [x,y,z,log w,log l,log h,sin,cos,v…]) (det/target.py:49-64)."""
+        return torch.cat([boxes[..., :3], boxes[..., 3:6].log(), boxes[..., 6:7].sin(), boxes[..., 6:7].cos(),
+                          boxes[..., 7:]], dim=-1)
+
+    def sample(self, cls_pred, box_pred, gt):
+        """gt = dict(boxes (bs, G, D) decoded, labels (bs, G), count (bs,)); returns dense class / box targets and
+        regression weights for every prediction, and keeps ``self.indices`` (bs, G) for the motion head."""
+        bs, num_pred, num_cls = cls_pred.shape
+        labels, count = gt["labels"], gt["count"]
+        valid = torch.arange(labels.shape[1], device=labels.device)[None] < count[:, None]
+        target = self.encode_reg_target(gt["boxes"])[..., : box_pred.shape[-1]]
+        weights = torch.logical_not(target.isnan()).to(target.dtype)
+        if self.cls_wise_reg_weights is not None:
+            for cls, w in self.cls_wise_reg_weights.items():
+                weights = torch.where((labels == cls)[..., None], _const(w, weights), weights)
+        with torch.no_grad():  # the matching is not differentiated (the reference detaches the cost)
+            cls_cost = _focal_cost(cls_pred, labels, self.alpha, self.gamma, self.eps) * self.cls_weight
+            box_cost = ((box_pred[:, :, None] - target[:, None]).abs() * weights[:, None]
+                        * _const(self.reg_weights, box_pred)).sum(-1) * self.box_weight
+            cost = cls_cost + box_cost
+            cost = torch.where(torch.isneginf(cost) | torch.isnan(cost), 1e8, cost)
+            index = linear_assignment(cost.transpose(1, 2).contiguous(), count)
+        index = torch.where(valid, index, torch.full_like(index, -1))
+        self.indices = index
+        cls_target = _scatter_rows(num_pred, index, labels, fill=num_cls)
+        return cls_target, _scatter_rows(num_pred, index, target), _scatter_rows(num_pred, index, weights)
+
+
+@BBOX_SAMPLERS.register_module()
+class SparsePoint3DTarget:
+    """Poly-line targets: focal class cost + permutation-invariant smooth-L1 line cost (map/match_cost.py),
+    Hungarian matching, targets taken in the best point order of each matched ground-truth line."""
+
+    def __init__(self, assigner=None, num_dn_groups=0, dn_noise_scale=0.5, max_dn_gt=32, add_neg_dn=True,
+                 num_temp_dn_groups=0, num_cls=3, num_sample=20, roi_size=(30, 60)):
+        if num_dn_groups or num_temp_dn_groups:
+            raise NotImplementedError("denoising queries are off in the HiP-AD configs")
+        cost = (assigner or {}).get("cost", {})
+        cls_cost, reg_cost = cost.get("cls_cost", {}), cost.get("reg_cost", {})
+        if cost.get("iou_cost") is not None or not reg_cost.get("permute", False):
+            raise NotImplementedError("only MapQueriesCost(FocalLossCost, LinesL1Cost(permute=True)) is implemented")
+        self.cls_cost_weight = cls_cost.get("weight", 1.0)
+        self.reg_cost_weight, self.reg_cost_beta = reg_cost.get("weight", 1.0), reg_cost.get("beta", 0.0)
+        self.num_cls, self.num_sample, self.roi_size = num_cls, num_sample, roi_size
+        self.dn_metas = None
+
+    def sample(self, cls_pred, pts_pred, gt):
+        """gt = dict(pts (bs, G, num_permute, num_sample*2), labels (bs, G), count (bs,))."""
+        bs, num_pred, num_cls = cls_pred.shape
+        labels, count, pts = gt["labels"], gt["count"], gt["pts"]
+        valid = torch.arange(labels.shape[1], device=labels.device)[None] < count[:, None]
+        with torch.no_grad():  # the matching is not differentiated
+            pred_n = _normalize_line(pts_pred, self.num_sample, self.roi_size)
+            gt_n = _normalize_line(pts, self.num_sample, self.roi_size)
+            cls_cost = _focal_cost(cls_pred, labels) * self.cls_cost_weight
+            diff = (pred_n[:, :, None, None] - gt_n[:, None]).abs()                 # (bs, P, G, perm, 2*pts)
+            dist = _smooth_l1(diff, self.reg_cost_beta).sum(-1) / (pts_pred.shape[-1] // 2)
+            reg_cost, perm = dist.min(dim=-1)                                         # (bs, P, G)
+            cost = torch.nan_to_num(cls_cost + reg_cost * self.reg_cost_weight)
+            index = linear_assignment(cost.transpose(1, 2).contiguous(), count)
+        index = torch.where(valid, index, torch.full_like(index, -1))
+        # point order of ground-truth line g as seen from its matched prediction
+        best = torch.gather(perm.transpose(1, 2), 2, index.clamp(min=0)[..., None]).squeeze(-1)   # (bs, G)
+        ordered = torch.gather(pts, 2, best[..., None, None].expand(-1, -1, 1, pts.shape[-1])).squeeze(2)
+        cls_target = _scatter_rows(num_pred, index, labels, fill=num_cls)
+        box_target = _scatter_rows(num_pred, index, ordered)
+        return cls_target, box_target, _scatter_rows(num_pred, index, torch.ones_like(ordered))
+
+
+def _closest_mode(reg_pred, reg_target, reg_weight):
+    """(bs, N, modes, ts, 2) offsets vs (bs, N, ts, 2): index of the mode whose cumulative trajectory is closest
+    (mean masked L2), reference motion/target.py:5-19 = plan/target.py:7-21."""
+    dist = torch.linalg.norm(reg_target.cumsum(dim=-2).unsqueeze(2) - reg_pred.cumsum(dim=-2), dim=-1)
+    return (dist * reg_weight.unsqueeze(2)).mean(dim=-1).argmin(dim=-1)
+
+
+def _take_mode(reg_pred, mode_idx):
+    ts, d = reg_pred.shape[-2:]
+    return torch.gather(reg_pred, 2, mode_idx[..., None, None, None].expand(-1, -1, 1, ts, d)).squeeze(2)
+
+
+@BBOX_SAMPLERS.register_module()
+class SparseMotionTarget:
+    def sample(self, reg_pred, gt, det_index):
+        """reg_pred (bs, A, modes, ts, 2); gt = dict(trajs (bs, G, ts, 2), masks (bs, G, ts), count); det_index
+        (bs, G) = the box matching of the last decoder layer (sparse_onedecoder.py:1287)."""
+        num_anchor = reg_pred.shape[1]
+        reg_target = _scatter_rows(num_anchor, det_index, gt["trajs"].to(reg_pred.dtype))
+        reg_weight = _scatter_rows(num_anchor, det_index, gt["masks"].to(reg_pred.dtype))
+        num_pos = (det_index >= 0).sum().to(reg_pred.dtype)
+        mode = _closest_mode(reg_pred, reg_target, reg_weight)
+        return mode, reg_weight.any(dim=-1), _take_mode(reg_pred, mode), reg_target, reg_weight, num_pos
+
+
+class _PlanTargetBase:
+    def __init__(self, ego_fut_ts=6, ego_fut_cmd=3, ego_fut_mode=3):
+        self.ego_fut_ts, self.ego_fut_cmd, self.ego_fut_mode = ego_fut_ts, ego_fut_cmd, ego_fut_mode
+
+    def _select_command(self, cls_pred, reg_pred, data):
+        bs = reg_pred.shape[0]
+        cls_pred = cls_pred.reshape(bs, self.ego_fut_cmd, 1, -1)
+        reg_pred = reg_pred.reshape(bs, self.ego_fut_cmd, 1, -1, self.ego_fut_ts, 2)
+        if self.ego_fut_cmd > 1:
+            rows = torch.arange(bs, device=reg_pred.device)
+            cmd = data["gt_ego_fut_cmd"].argmax(dim=-1)
+            return cls_pred[rows, cmd], reg_pred[rows, cmd]
+        return cls_pred[:, 0], reg_pred[:, 0]
+
+
+@BBOX_SAMPLERS.register_module()
+class SparsePlanTarget(_PlanTargetBase):
+    def sample(self, cls_pred, reg_pred, gt_reg_target, gt_reg_mask, data):
+        gt_reg_target, gt_reg_mask = gt_reg_target.unsqueeze(1), gt_reg_mask.unsqueeze(1)
+        cls_pred, reg_pred = self._select_command(cls_pred, reg_pred, data)
+        mode = _closest_mode(reg_pred, gt_reg_target, gt_reg_mask)
+        return cls_pred, mode, gt_reg_mask.any(dim=-1), _take_mode(reg_pred, mode), gt_reg_target, gt_reg_mask
+
+
+@BBOX_SAMPLERS.register_module()
+class AlignPlanTarget(_PlanTargetBase):
+    def sample(self, cls_pred, reg_pred, gt_reg_target, gt_reg_mask, data, ref_target):
+        gt_reg_target, gt_reg_mask = gt_reg_target.unsqueeze(1), gt_reg_mask.unsqueeze(1)
+        cls_pred, reg_pred = self._select_command(cls_pred, reg_pred, data)
+        return cls_pred, ref_target, gt_reg_mask.any(dim=-1), _take_mode(reg_pred, ref_target), gt_reg_target, gt_reg_mask
+
+
+# ------------------------------------------------------------------------------------------------
+# ground truth: ragged lists (the reference's data format) -> padded tensors
+# ------------------------------------------------------------------------------------------------
+def _pad(items, length, fill, device):
+    tail = tuple(items[0].shape[1:]) if len(items) else ()
+    out = torch.full((len(items), length) + tail, fill, dtype=items[0].dtype, device=device)
+    count = torch.zeros(len(items), dtype=torch.int32)
+    for i, t in enumerate(items):
+        n = min(len(t), length)
+        out[i, :n] = t[:n].to(device)
+        count[i] = n
+    return out, count.to(device)
+
+
+def pad_ground_truth(data, device=None, max_det=None, max_map=None):
+    """``gt_padded`` entry for ``data``: the reference's ragged lists (``gt_bboxes_3d`` / ``gt_labels_3d`` /
+    ``gt_map_pts`` / ``gt_map_labels`` / ``gt_agent_fut_trajs`` / ``gt_agent_fut_masks``) as padded tensors +
+    counts.  Host-side helper (runs outside the captured step)."""
+    out = {}
+    if "gt_bboxes_3d" in data:
+        boxes = list(data["gt_bboxes_3d"])
+        device = device or boxes[0].device
+        g = max_det or max(1, max(len(b) for b in boxes))
+        pb, count = _pad(boxes, g, 1.0, device)  # padding boxes have size 1 so log() stays finite
+        pl, _ = _pad(list(data["gt_labels_3d"]), g, 0, device)
+        out["det"] = dict(boxes=pb, labels=pl, count=count)
+        if "gt_agent_fut_trajs" in data:
+            pt, _ = _pad(list(data["gt_agent_fut_trajs"]), g, 0.0, device)
+            pm, _ = _pad(list(data["gt_agent_fut_masks"]), g, 0.0, device)
+            out["motion"] = dict(trajs=pt, masks=pm, count=count)
+    if "gt_map_pts" in data:
+        pts = [p.flatten(2, 3) if p.dim() == 4 else p for p in data["gt_map_pts"]]
+        device = device or pts[0].device
+        g = max_map or max(1, max(len(p) for p in pts))
+        pp, count = _pad(pts, g, 0.0, device)
+        pl, _ = _pad(list(data["gt_map_labels"]), g, 0, device)
+        out["map"] = dict(pts=pp, labels=pl, count=count)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# the decoder's loss()
+# ------------------------------------------------------------------------------------------------
+def _num_pos(mask):
+    return torch.clamp(reduce_mean(mask.sum().to(torch.float32)), min=1.0)
+
+
+class DecoderLoss:
+    """``loss()`` of SparseOneDecoder (mixed into the class in sparse_onedecoder.py)."""
+
+    def loss(self, det_output, map_output, ego_output, plan_output, motion_output, scenes_output, data):
+        gt = data.get("gt_padded") or pad_ground_truth(data)
+        losses = {}
+        if "det" in self.task_select:
+            losses.update(self.loss_det(det_output, gt["det"]))
+        if "map" in self.task_select:
+            losses.update(self.loss_map(map_output, gt["map"]))
+        if "ego" in self.task_select:
+            losses.update(self.loss_ego(ego_output, data))
+        if "motion" in self.task_select:
+            losses.update(self.loss_motion(motion_output, gt["motion"]))
+        if "plan" in self.task_select:
+            losses.update(self.loss_plan(plan_output, data))
+        return losses
+
+    def _add(self, output, key, layer, value):
+        if self.combine_layer_loss:
+            output[key] = output.get(key, 0.0) + value
+        else:
+            output[f"{key}_{layer}"] = value
+
+    def _matched_losses(self, outs, gt, sampler, reg_weights, loss_cls, loss_reg, prefix, reg_keys):
+        output = {}
+        for layer, (cls, reg, qt) in enumerate(zip(outs["classification"], outs["prediction"], outs["quality"])):
+            reg = reg[..., : len(reg_weights)]
+            cls_target, reg_target, weights = sampler.sample(cls, reg, gt)
+            matched = torch.logical_not(torch.all(reg_target == 0, dim=-1))
+            num_pos = _num_pos(matched)
+            rows = matched
+            if self.cls_threshold_to_reg > 0:
+                rows = rows & (cls.max(dim=-1).values.sigmoid() > self.cls_threshold_to_reg)
+            cls_loss = loss_cls(cls.flatten(end_dim=1), cls_target.flatten(end_dim=1), avg_factor=num_pos)
+            weights = (weights * _const(reg_weights, reg)).flatten(end_dim=1)
+            reg_target = reg_target.flatten(end_dim=1)
+            reg_target = torch.where(reg_target.isnan(), 0.0, reg_target)
+            reg_loss = loss_reg(reg.flatten(end_dim=1), reg_target, weight=weights, avg_factor=num_pos,
+                                prefix=prefix, suffix=f"_{layer}", quality=None if qt is None else qt.flatten(end_dim=1),
+                                cls_target=cls_target.flatten(end_dim=1), row_mask=rows.flatten())
+            self._add(output, f"{prefix}loss_cls", layer, cls_loss)
+            for key in reg_keys:
+                self._add(output, f"{prefix}loss_{key}", layer, reg_loss[f"{prefix}loss_{key}_{layer}"])
+        return output
+
+    def loss_det(self, outs, gt):
+        return self._matched_losses(outs, gt, self.det_sampler, self.det_reg_weights, self.loss_det_cls,
+                                    self.loss_det_reg, "det_", ("box", "cns", "yns"))
+
+    def loss_map(self, outs, gt):
+        def line_loss(line, target, weight=None, row_mask=None, **kw):  # SparseLineLoss has no row selection of its own
+            return self.loss_map_reg(line, target, weight=weight * row_mask.to(weight.dtype)[:, None], **kw)
+        return self._matched_losses(outs, gt, self.map_sampler, self.map_reg_weights, self.loss_map_cls,
+                                    line_loss, "map_", ("line",))
+
+    def loss_ego(self, outs, data):
+        if not self.with_supervise_ego_status:
+            raise NotImplementedError("ego trajectory supervision is unused by the HiP-AD configs")
+        output = {}
+        for layer, status in enumerate(outs["status"]):
+            loss = self.loss_ego_status(status.squeeze(1), data["ego_status"], weight=data["ego_status_mask"])
+            self._add(output, "ego_loss_status", layer, torch.nan_to_num(loss))
+        return output
+
+    def loss_motion(self, outs, gt):
+        output = {}
+        det_index = self.det_sampler.indices  # matching of the LAST decoder layer, for every motion layer
+        for layer, (cls, reg) in enumerate(zip(outs["classification"], outs["prediction"])):
+            cls_target, cls_weight, best, reg_target, reg_weight, num_pos = self.motion_sampler.sample(reg, gt, det_index)
+            num_pos = torch.clamp(reduce_mean(num_pos), min=1.0)
+            cls_loss = self.loss_motion_cls(cls.flatten(end_dim=1), cls_target.flatten(end_dim=1),
+                                            weight=cls_weight.flatten(end_dim=1), avg_factor=num_pos)
+            reg_loss = self.loss_motion_reg(best.flatten(end_dim=1).cumsum(dim=-2), reg_target.flatten(end_dim=1).cumsum(dim=-2),
+                                            weight=reg_weight.flatten(end_dim=1).unsqueeze(-1), avg_factor=num_pos)
+            self._add(output, "motion_loss_cls", layer, cls_loss)
+            self._add(output, "motion_loss_reg", layer, reg_loss)
+        return output
+
+    # ---- planning ---------------------------------------------------------------------------------
+    def _plan_slice(self, cls, reg, kind):
+        modes = reg.size(2) // self.plan_anchor_group
+        s = self.ego_fut_cmd * modes * self.plan_anchor_types.index(kind)
+        return cls[:, :, s:s + self.ego_fut_cmd * modes], reg[:, :, s:s + self.ego_fut_cmd * modes]
+
+    @staticmethod
+    def _plan_gt(data, kind):
+        key = "fut" if kind[0] in ("temp", "speed") else "spat"
+        return data[f"gt_ego_{key}_trajs_{kind[1]}"], data[f"gt_ego_{key}_masks_{kind[1]}"]
+
+    def _plan_terms(self, cls, target, cls_weight, best, gt_target, gt_mask):
+        cls_loss = self.loss_plan_cls(cls.flatten(end_dim=1), target.flatten(end_dim=1), weight=cls_weight.flatten(end_dim=1))
+        reg_loss = self.loss_plan_reg(best.cumsum(dim=-2).flatten(end_dim=1), gt_target.cumsum(dim=-2).flatten(end_dim=1),
+                                      weight=gt_mask.flatten(end_dim=1).unsqueeze(-1))
+        return cls_loss, reg_loss
+
+    def loss_plan(self, outs, data):
+        output = {}
+        kinds = []
+        for t in self.plan_anchor_types:
+            if t[0] not in kinds:
+                kinds.append(t[0])
+        for layer, (cls, reg) in enumerate(zip(outs["classification"], outs["prediction"])):
+            total = {k: [0.0, 0.0] for k in ("temp", "spat", "speed")}
+            ref_cls, ref_reg = self._plan_slice(cls, reg, self.plan_anchor_refer)
+            ref_gt, ref_mask = self._plan_gt(data, self.plan_anchor_refer)
+            # the winning mode of the reference group decides the target mode of every other group
+            _, ref_target, ref_weight, _, _, _ = self.plan_sampler.sample(ref_cls, ref_reg, ref_gt, ref_mask, data)
+            speed = {}
+            for kind in self.plan_anchor_types:
+                p_cls, p_reg = self._plan_slice(cls, reg, kind)
+                g_traj, g_mask = self._plan_gt(data, kind)
+                if kind[0] in ("temp", "spat"):
+                    a_cls, _, _, best, g_t, g_m = self.align_sampler.sample(p_cls, p_reg, g_traj, g_mask, data, ref_target)
+                    c, r = self._plan_terms(a_cls, ref_target, ref_weight, best, g_t, g_m)
+                    total[kind[0]][0] = total[kind[0]][0] + c
+                    total[kind[0]][1] = total[kind[0]][1] + r
+                elif kind[0] == "speed":
+                    grp = speed.setdefault(kind[1], dict(cls=[], reg=[], gt=(g_traj, g_mask), areas=[]))
+                    grp["cls"].append(p_cls); grp["reg"].append(p_reg); grp["areas"].append(kind[2])
+                else:
+                    raise NotImplementedError(kind)
+            for grp in speed.values():
+                c, r = self._speed_terms(grp, ref_target, data)
+                total["speed"][0] = total["speed"][0] + c
+                total["speed"][1] = total["speed"][1] + r
+            for k in kinds:
+                self._add(output, f"plan_loss_{k}_cls", layer, total[k][0])
+                self._add(output, f"plan_loss_{k}_reg", layer, total[k][1])
+        return output
+
+    def _speed_terms(self, grp, ref_target, data):
+        """Speed groups (reference :1371-1443): every speed bucket contributes the logit and the trajectory of the
+        reference mode; the bucket of the ground-truth average speed is the class target."""
+        g_traj, g_mask = grp["gt"]
+        rows = torch.arange(ref_target.shape[0], device=ref_target.device)
+        logits, trajs = [], []
+        for p_cls, p_reg in zip(grp["cls"], grp["reg"]):
+            a_cls, _, _, a_reg, _, _ = self.align_sampler.sample(p_cls, p_reg, g_traj, g_mask, data, ref_target)
+            logits.append(a_cls.squeeze(1)[rows, ref_target.squeeze(-1)][:, None, None])
+            trajs.append(a_reg[:, :, None])
+        logits, trajs = torch.cat(logits, dim=-1), torch.cat(trajs, dim=-3)       # (bs,1,K), (bs,1,K,ts,2)
+        sp_traj, sp_mask = self._plan_gt(data, self.plan_speed_refer)
+        sp_traj, sp_mask = sp_traj.unsqueeze(1), sp_mask.unsqueeze(1)
+        interval = 1 / float(self.plan_speed_refer[1].split("hz")[0])
+        speed = torch.linalg.norm(sp_traj, dim=-1).sum(-1) / (sp_mask.sum(-1) * interval + 1e-4)
+        bucket = torch.ones_like(speed, dtype=torch.long)
+        for i, (lo, hi) in enumerate(grp["areas"]):
+            bucket = torch.where((speed >= lo) & (speed < hi), torch.full_like(bucket, i), bucket)
+        bs, _, k = logits.shape
+        cls_k = logits.reshape(bs, self.ego_fut_cmd, 1, k)
+        reg_k = trajs.reshape(bs, self.ego_fut_cmd, 1, k, self.ego_fut_ts, 2)
+        if self.ego_fut_cmd > 1:
+            cmd = data["gt_ego_fut_cmd"].argmax(dim=-1)
+            cls_k, reg_k = cls_k[rows, cmd], reg_k[rows, cmd]
+        else:
+            cls_k, reg_k = cls_k[:, 0], reg_k[:, 0]
+        return self._plan_terms(cls_k, bucket, sp_mask.any(dim=-1), _take_mode(reg_k, bucket),
+                                g_traj.unsqueeze(1), g_mask.unsqueeze(1))

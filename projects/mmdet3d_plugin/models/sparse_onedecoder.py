@@ -12,7 +12,7 @@ Covered: everything the two HiP-AD configs switch on (det / map / plan / ego que
 command + target-point embedding, ego status supervision, plan += ego feature, temporal caches,
 closed-loop bank rotation).  Not covered (off in those configs, raise at construction): scene
 tokens, attention masks, point-level map/plan tokens, top-k mode pruning.
-Loss / post-processing: see ``loss`` below (SURVEY.md section 8f row 1 -- next).
+Loss: ``criterion.DecoderLoss`` (static shapes, device-side Hungarian matching).  Post-processing: next row (8f/3).
 """
 import copy
 from types import SimpleNamespace
@@ -28,6 +28,7 @@ from projects.mmdet3d_plugin.core.box3d import COS_YAW, SIN_YAW
 
 from .attention import gen_sineembed_for_position
 from .blocks import linear_relu_ln
+from .criterion import DecoderLoss
 
 __all__ = ["SparseOneDecoder"]
 
@@ -72,7 +73,7 @@ def _optional(cfg, registry, fallback=None):
 
 
 @HEADS.register_module()
-class SparseOneDecoder(BaseModule):
+class SparseOneDecoder(DecoderLoss, BaseModule):
     def __init__(self, ffn: dict = None, init_cfg: dict = None, custom_op: dict = None, embed_dims: int = 256,
                  num_decoder: int = 6, num_single_frame_decoder: int = -1, decouple_attn: bool = True,
                  with_instance_id: bool = True, cls_threshold_to_reg: float = -1, norm_layer: dict = None,
@@ -432,11 +433,7 @@ class SparseOneDecoder(BaseModule):
         return det_output, map_output, ego_output, plan_output, motion_output, scenes_output
 
     # ------------------------------------------------------------------------------------
-    def loss(self, det_output, map_output, ego_output, plan_output, motion_output, scenes_output, data):
-        raise NotImplementedError(
-            "the training losses / target assignment (reference sparse_onedecoder.py:1094-1579) are the first 'next' "
-            "row of SURVEY.md section 8f and not part of this build yet; bench.py drives backward with a surrogate "
-            "objective over every head output")
+    # loss(): DecoderLoss (criterion.py) -- target assignment and every loss term on the device
 
     def post_process(self, *args, **kwargs):
         raise NotImplementedError("result decoding (reference sparse_onedecoder.py:1581-1605) is a 'next' row (8f/3)")

@@ -232,14 +232,24 @@ def install():
          Sequential=Sequential)
     _mod("mmcv.runner.base_module", BaseModule=BaseModule, Sequential=Sequential)
     _mod("mmdet")
-    _mod("mmdet.core", reduce_mean=lambda x: x)
     _mod("mmdet.core.bbox")
     _mod("mmdet.core.bbox.builder", BBOX_SAMPLERS=BBOX_SAMPLERS, BBOX_CODERS=BBOX_CODERS,
          BBOX_ASSIGNERS=BBOX_ASSIGNERS)
-    _mod("mmdet.core.bbox.match_costs")
+    import _mmdet_losses as ML  # restated mmdet==2.28.2 loss primitives (third-party, absent here)
+    for cls in (ML.FocalLoss, ML.L1Loss, ML.CrossEntropyLoss, ML.GaussianFocalLoss):
+        LOSSES.register_module(module=cls)
+    MATCH_COST.register_module(module=ML.FocalLossCost)
+    build_match_cost = lambda cfg: build_from_cfg(cfg, MATCH_COST)  # noqa: E731
+    build_assigner = lambda cfg, **kw: build_from_cfg(cfg, BBOX_ASSIGNERS)  # noqa: E731
+    _mod("mmdet.core", reduce_mean=lambda x: x, build_assigner=build_assigner,
+         build_sampler=lambda cfg, **kw: build_from_cfg(cfg, BBOX_SAMPLERS))
+    _mod("mmdet.core.bbox.assigners", AssignResult=ML.AssignResult, BaseAssigner=ML.BaseAssigner)
+    _mod("mmdet.core.bbox.match_costs", build_match_cost=build_match_cost)
     _mod("mmdet.core.bbox.match_costs.builder", MATCH_COST=MATCH_COST)
     _mod("mmdet.models", HEADS=HEADS, LOSSES=LOSSES, DETECTORS=DETECTORS,
          build_loss=lambda cfg: build_from_cfg(cfg, LOSSES))
+    _mod("mmdet.models.builder", LOSSES=LOSSES, HEADS=HEADS, DETECTORS=DETECTORS)
+    _mod("mmdet.models.losses", l1_loss=ML.l1_loss, smooth_l1_loss=ML.smooth_l1_loss)
     _mod("flash_attn")
     _mod("flash_attn.flash_attn_interface", flash_attn_unpadded_kvpacked_func=None,
          flash_attn_varlen_kvpacked_func=None)

@@ -359,7 +359,66 @@ def gen_decoder():
     save("decoder_stage2", **out)
 
 
-GENS = {"daf": gen_daf, "format": gen_format, "project": gen_project, "dfa": gen_keypoints_and_dfa,
+def gen_losses():
+    """The reference's SparseOneDecoder.loss (sparse_onedecoder.py:1094-1579) with its own samplers and loss
+    modules, on seeded head outputs and ragged ground truth (tests/golden/loss_case.py).  The mmdet primitives
+    underneath are the restatements of tests/golden/_mmdet_losses.py (mmdet is not installed)."""
+    import copy
+    import loss_case as LC
+    from seeded import checksum
+    for m in ("models.base_target", "models.det.target", "models.det.losses", "models.map.target", "models.map.match_cost",
+              "models.map.loss", "models.plan.target", "models.motion.target", "models.instance_bank",
+              "models.plan.instance_bank", "models.ego.instance_bank", "models.plan.blocks", "models.ego.blocks",
+              "models.motion.blocks", "models.attention", "models.separate_attn"):
+        S.ref_import(m)
+    ref_dec = S.ref_import("models.sparse_onedecoder")
+    txt = cfg_text().replace('"/opt/data/private/project/HiP-AD"', repr(S.REF))
+    ns = {}
+    exec(compile(txt, "hipad_b2d_stage2.py", "exec"), ns)
+    od = copy.deepcopy(ns["model"]["head"]["onedecoder_head"])
+    dec = object.__new__(ref_dec.SparseOneDecoder)   # only loss() runs: no parameters, no banks
+    torch.nn.Module.__init__(dec)
+    build = S.build_from_cfg
+    for k in ("det", "map", "plan", "align", "motion"):
+        setattr(dec, f"{k}_sampler", build(od[f"{k}_sampler"], S.BBOX_SAMPLERS))
+    for k in ("loss_det_cls", "loss_det_reg", "loss_map_cls", "loss_map_reg", "loss_ego_status", "loss_plan_cls",
+              "loss_plan_reg", "loss_motion_cls", "loss_motion_reg"):
+        setattr(dec, k, build(od[k], S.LOSSES))
+    dec.task_select = od["task_select"]
+    dec.det_reg_weights, dec.map_reg_weights = od["det_reg_weights"], od["map_reg_weights"]
+    dec.cls_threshold_to_reg = od["cls_threshold_to_reg"]
+    dec.combine_layer_loss = od.get("combine_layer_loss", True)
+    dec.with_supervise_ego_status = od["with_supervise_ego_status"]
+    dec.plan_anchor_types = ns["plan_anchor_types"]
+    dec.plan_anchor_group = len(ns["plan_anchor_types"])
+    dec.plan_anchor_refer, dec.plan_speed_refer = od["plan_anchor_refer"], od["plan_speed_refer"]
+    dec.ego_fut_ts, dec.ego_fut_cmd, dec.ego_fut_mode = ns["ego_fut_ts"], ns["ego_fut_cmd"], ns["ego_fut_mode"]
+    outs = LC.head_outputs(requires_grad=True)
+    data = LC.ground_truth()
+    losses = dec.loss(*outs, data)
+    total = sum(losses.values())
+    total.backward()
+    out = {k: v.detach() for k, v in losses.items()}
+    out["total"] = total.detach()
+    out["loss_keys"] = np.array(sorted(losses))
+    det, mp, ego, plan, motion, _ = outs
+    out["input_checksum"] = checksum(torch.cat([det["classification"][0].flatten(), plan["prediction"][5].flatten()]))
+    for name, group, keys in (("det", det, ("classification", "prediction", "quality")), ("map", mp, ("classification", "prediction")),
+                              ("ego", ego, ("status",)), ("plan", plan, ("classification", "prediction")),
+                              ("motion", motion, ("classification", "prediction"))):
+        for key in keys:
+            for li in (0, 5):
+                g = group[key][li].grad
+                out[f"grad_{name}_{key}_{li}_sum"] = checksum(g)
+                out[f"grad_{name}_{key}_{li}_head"] = g.flatten()[:: max(1, g.numel() // 4096)][:4096]
+    # the matching itself (last layer), for a direct check of the device Hungarian kernel
+    pi, ti = dec.det_sampler.indices[0]
+    out["det_match_pred_b0"], out["det_match_gt_b0"] = pi, ti
+    print({k: float(v) for k, v in losses.items()})
+    save("losses_stage2", **out)
+
+
+GENS = {"losses": gen_losses, "daf": gen_daf, "format": gen_format, "project": gen_project, "dfa": gen_keypoints_and_dfa,
         "decoder": gen_decoder}
 
 if __name__ == "__main__":
