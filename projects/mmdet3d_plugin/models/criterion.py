@@ -43,13 +43,20 @@ def _const(values, like):
     return t
 
 
-def _reduce(loss, weight=None, avg_factor=None):
-    """mmdet's weight_reduce_loss for reduction='mean': mean of the elements, or sum / (avg_factor + eps)."""
+def _reduce(loss, weight=None, avg_factor=None, layers=1):
+    """mmdet's weight_reduce_loss for reduction='mean': mean of the elements, or sum / (avg_factor + eps).
+
+    ``layers`` > 1: the leading dimension stacks that many decoder layers (layer-major); the reduction is done
+    per layer (``avg_factor`` may be a (layers,) tensor) and a (layers,) vector is returned -- the six decoder
+    layers are evaluated by ONE pass of every op instead of six."""
     if weight is not None:
         if weight.dim() == loss.dim() - 1:
             weight = weight.unsqueeze(-1)
         loss = loss * weight.to(loss.dtype)
-    return loss.mean() if avg_factor is None else loss.sum() / (avg_factor + _EPS)
+    if layers == 1:
+        return loss.mean() if avg_factor is None else (loss.sum() / (avg_factor + _EPS)).reshape(())
+    per = loss.reshape(layers, -1)
+    return per.mean(dim=1) if avg_factor is None else per.sum(dim=1) / (avg_factor + _EPS)
 
 
 def linear_assignment(cost_gt_major, count):
@@ -81,14 +88,14 @@ class FocalLoss(nn.Module):
             raise NotImplementedError("only the sigmoid / logits / mean variant used by the HiP-AD configs")
         self.gamma, self.alpha, self.loss_weight = gamma, alpha, loss_weight
 
-    def forward(self, pred, target, weight=None, avg_factor=None):
+    def forward(self, pred, target, weight=None, avg_factor=None, layers=1):
         c = pred.shape[-1]
         t = F.one_hot(target, c + 1)[..., :c].to(pred.dtype)
         p = pred.sigmoid()
         pt = (1 - p) * t + p * (1 - t)
         focal = (self.alpha * t + (1 - self.alpha) * (1 - t)) * pt.pow(self.gamma)
         loss = F.binary_cross_entropy_with_logits(pred, t, reduction="none") * focal
-        return self.loss_weight * _reduce(loss, weight, avg_factor)
+        return self.loss_weight * _reduce(loss, weight, avg_factor, layers)
 
 
 @LOSSES.register_module()
@@ -97,8 +104,8 @@ class L1Loss(nn.Module):
         super().__init__()
         self.loss_weight = loss_weight
 
-    def forward(self, pred, target, weight=None, avg_factor=None):
-        return self.loss_weight * _reduce((pred - target).abs(), weight, avg_factor)
+    def forward(self, pred, target, weight=None, avg_factor=None, layers=1):
+        return self.loss_weight * _reduce((pred - target).abs(), weight, avg_factor, layers)
 
 
 @LOSSES.register_module()
@@ -111,9 +118,9 @@ class CrossEntropyLoss(nn.Module):
             raise NotImplementedError("only use_sigmoid=True is used by the HiP-AD configs")
         self.loss_weight = loss_weight
 
-    def forward(self, pred, target, weight=None, avg_factor=None):
+    def forward(self, pred, target, weight=None, avg_factor=None, layers=1):
         loss = F.binary_cross_entropy_with_logits(pred, target.to(pred.dtype), reduction="none")
-        return self.loss_weight * _reduce(loss, weight, avg_factor)
+        return self.loss_weight * _reduce(loss, weight, avg_factor, layers)
 
 
 @LOSSES.register_module()
@@ -122,11 +129,11 @@ class GaussianFocalLoss(nn.Module):
         super().__init__()
         self.alpha, self.gamma, self.loss_weight = alpha, gamma, loss_weight
 
-    def forward(self, pred, target, weight=None, avg_factor=None):
+    def forward(self, pred, target, weight=None, avg_factor=None, layers=1):
         eps = 1e-12
         pos = -(pred + eps).log() * (1 - pred).pow(self.alpha) * target.eq(1).to(pred.dtype)
         neg = -(1 - pred + eps).log() * pred.pow(self.alpha) * (1 - target).pow(self.gamma)
-        return self.loss_weight * _reduce(pos + neg, weight, avg_factor)
+        return self.loss_weight * _reduce(pos + neg, weight, avg_factor, layers)
 
 
 def _smooth_l1(diff_abs, beta):
@@ -141,8 +148,8 @@ class LinesL1Loss(nn.Module):
         super().__init__()
         self.loss_weight, self.beta = loss_weight, beta
 
-    def forward(self, pred, target, weight=None, avg_factor=None):
-        loss = _reduce(_smooth_l1((pred - target).abs(), self.beta), weight, avg_factor)
+    def forward(self, pred, target, weight=None, avg_factor=None, layers=1):
+        loss = _reduce(_smooth_l1((pred - target).abs(), self.beta), weight, avg_factor, layers)
         return loss / (pred.shape[-1] // 2) * self.loss_weight
 
 
@@ -161,10 +168,11 @@ class SparseLineLoss(nn.Module):
         self.loss_line = build_from_cfg(loss_line, LOSSES)
         self.num_sample, self.roi_size = num_sample, roi_size
 
-    def forward(self, line, line_target, weight=None, avg_factor=None, prefix="", suffix="", **kwargs):
+    def forward(self, line, line_target, weight=None, avg_factor=None, prefix="", suffix="", layers=1, **kwargs):
         line = _normalize_line(line, self.num_sample, self.roi_size)
         line_target = _normalize_line(line_target, self.num_sample, self.roi_size)
-        return {f"{prefix}loss_line{suffix}": self.loss_line(line, line_target, weight=weight, avg_factor=avg_factor)}
+        return {f"{prefix}loss_line{suffix}": self.loss_line(line, line_target, weight=weight, avg_factor=avg_factor,
+                                                             layers=layers)}
 
 
 @LOSSES.register_module()
@@ -181,17 +189,17 @@ class SparseBox3DLoss(nn.Module):
         self.loss_yns = build_from_cfg(loss_yawness, LOSSES)
 
     def forward(self, box, box_target, weight=None, avg_factor=None, prefix="", suffix="", quality=None,
-                cls_target=None, row_mask=None, **kwargs):
+                cls_target=None, row_mask=None, layers=1, **kwargs):
         m = None if row_mask is None else row_mask.to(box.dtype)
         w = weight if m is None else (m[:, None] if weight is None else weight * m[:, None])
-        out = {f"{prefix}loss_box{suffix}": self.loss_box(box, box_target, weight=w, avg_factor=avg_factor)}
+        out = {f"{prefix}loss_box{suffix}": self.loss_box(box, box_target, weight=w, avg_factor=avg_factor, layers=layers)}
         if quality is not None:
             cns, yns = quality[..., CNS], quality[..., YNS].sigmoid()
             cns_target = torch.exp(-torch.norm(box_target[..., :3] - box[..., :3], p=2, dim=-1))
-            out[f"{prefix}loss_cns{suffix}"] = self.loss_cns(cns, cns_target, weight=m, avg_factor=avg_factor)
+            out[f"{prefix}loss_cns{suffix}"] = self.loss_cns(cns, cns_target, weight=m, avg_factor=avg_factor, layers=layers)
             yaw = slice(SIN_YAW, COS_YAW + 1)  # a slice, not an index list: list indices are uploaded at run time
             yns_target = (F.cosine_similarity(box_target[..., yaw], box[..., yaw], dim=-1) > 0).to(box.dtype)
-            out[f"{prefix}loss_yns{suffix}"] = self.loss_yns(yns, yns_target, weight=m, avg_factor=avg_factor)
+            out[f"{prefix}loss_yns{suffix}"] = self.loss_yns(yns, yns_target, weight=m, avg_factor=avg_factor, layers=layers)
         return out
 
 
@@ -401,12 +409,22 @@ def pad_ground_truth(data, device=None, max_det=None, max_map=None):
 # ------------------------------------------------------------------------------------------------
 # the decoder's loss()
 # ------------------------------------------------------------------------------------------------
-def _num_pos(mask):
-    return torch.clamp(reduce_mean(mask.sum().to(torch.float32)), min=1.0)
+def _stack_layers(tensors):
+    """[L x (bs, ...)] -> (L*bs, ...), layer-major."""
+    return torch.stack(list(tensors)).flatten(0, 1)
+
+
+def _tile(t, layers):
+    """(bs, ...) ground truth -> (L*bs, ...) matching _stack_layers."""
+    return t.repeat((layers,) + (1,) * (t.dim() - 1))
 
 
 class DecoderLoss:
-    """``loss()`` of SparseOneDecoder (mixed into the class in sparse_onedecoder.py)."""
+    """``loss()`` of SparseOneDecoder (mixed into the class in sparse_onedecoder.py).
+
+    All decoder layers are evaluated together: their outputs are stacked along the batch dimension, the ground
+    truth is tiled, every op (costs, the Hungarian kernel, scatters, loss formulas) runs once for the six layers,
+    and only the final reductions are per layer (each layer has its own ``num_pos``)."""
 
     def loss(self, det_output, map_output, ego_output, plan_output, motion_output, scenes_output, data):
         gt = data.get("gt_padded") or pad_ground_truth(data)
@@ -423,32 +441,37 @@ class DecoderLoss:
             losses.update(self.loss_plan(plan_output, data))
         return losses
 
-    def _add(self, output, key, layer, value):
+    def _add(self, output, key, per_layer):
+        """per_layer: (L,) vector of one loss term."""
         if self.combine_layer_loss:
-            output[key] = output.get(key, 0.0) + value
+            output[key] = output.get(key, 0.0) + per_layer.sum()
         else:
-            output[f"{key}_{layer}"] = value
+            for layer in range(per_layer.shape[0]):
+                output[f"{key}_{layer}"] = per_layer[layer]
 
     def _matched_losses(self, outs, gt, sampler, reg_weights, loss_cls, loss_reg, prefix, reg_keys):
+        layers = len(outs["classification"])
+        cls = _stack_layers(outs["classification"])
+        reg = _stack_layers(outs["prediction"])[..., : len(reg_weights)]
+        qt = None if outs["quality"][0] is None else _stack_layers(outs["quality"])
+        cls_target, reg_target, weights = sampler.sample(cls, reg, {k: _tile(v, layers) for k, v in gt.items()})
+        sampler.layers = layers
+        matched = torch.logical_not(torch.all(reg_target == 0, dim=-1))
+        num_pos = torch.clamp(reduce_mean(matched.reshape(layers, -1).sum(dim=1).to(torch.float32)), min=1.0)   # (L,)
+        rows = matched
+        if self.cls_threshold_to_reg > 0:
+            rows = rows & (cls.max(dim=-1).values.sigmoid() > self.cls_threshold_to_reg)
+        cls_loss = loss_cls(cls.flatten(end_dim=1), cls_target.flatten(end_dim=1), avg_factor=num_pos, layers=layers)
+        weights = (weights * _const(reg_weights, reg)).flatten(end_dim=1)
+        reg_target = reg_target.flatten(end_dim=1)
+        reg_target = torch.where(reg_target.isnan(), 0.0, reg_target)
+        reg_loss = loss_reg(reg.flatten(end_dim=1), reg_target, weight=weights, avg_factor=num_pos, prefix=prefix,
+                            quality=None if qt is None else qt.flatten(end_dim=1),
+                            cls_target=cls_target.flatten(end_dim=1), row_mask=rows.flatten(), layers=layers)
         output = {}
-        for layer, (cls, reg, qt) in enumerate(zip(outs["classification"], outs["prediction"], outs["quality"])):
-            reg = reg[..., : len(reg_weights)]
-            cls_target, reg_target, weights = sampler.sample(cls, reg, gt)
-            matched = torch.logical_not(torch.all(reg_target == 0, dim=-1))
-            num_pos = _num_pos(matched)
-            rows = matched
-            if self.cls_threshold_to_reg > 0:
-                rows = rows & (cls.max(dim=-1).values.sigmoid() > self.cls_threshold_to_reg)
-            cls_loss = loss_cls(cls.flatten(end_dim=1), cls_target.flatten(end_dim=1), avg_factor=num_pos)
-            weights = (weights * _const(reg_weights, reg)).flatten(end_dim=1)
-            reg_target = reg_target.flatten(end_dim=1)
-            reg_target = torch.where(reg_target.isnan(), 0.0, reg_target)
-            reg_loss = loss_reg(reg.flatten(end_dim=1), reg_target, weight=weights, avg_factor=num_pos,
-                                prefix=prefix, suffix=f"_{layer}", quality=None if qt is None else qt.flatten(end_dim=1),
-                                cls_target=cls_target.flatten(end_dim=1), row_mask=rows.flatten())
-            self._add(output, f"{prefix}loss_cls", layer, cls_loss)
-            for key in reg_keys:
-                self._add(output, f"{prefix}loss_{key}", layer, reg_loss[f"{prefix}loss_{key}_{layer}"])
+        self._add(output, f"{prefix}loss_cls", cls_loss.reshape(layers))
+        for key in reg_keys:
+            self._add(output, f"{prefix}loss_{key}", reg_loss[f"{prefix}loss_{key}"].reshape(layers))
         return output
 
     def loss_det(self, outs, gt):
@@ -464,24 +487,30 @@ class DecoderLoss:
     def loss_ego(self, outs, data):
         if not self.with_supervise_ego_status:
             raise NotImplementedError("ego trajectory supervision is unused by the HiP-AD configs")
+        layers = len(outs["status"])
+        status = _stack_layers(outs["status"]).squeeze(1)
+        loss = self.loss_ego_status(status, _tile(data["ego_status"], layers), weight=_tile(data["ego_status_mask"], layers),
+                                    layers=layers)
         output = {}
-        for layer, status in enumerate(outs["status"]):
-            loss = self.loss_ego_status(status.squeeze(1), data["ego_status"], weight=data["ego_status_mask"])
-            self._add(output, "ego_loss_status", layer, torch.nan_to_num(loss))
+        self._add(output, "ego_loss_status", torch.nan_to_num(loss).reshape(layers))
         return output
 
     def loss_motion(self, outs, gt):
+        layers = len(outs["classification"])
+        cls, reg = _stack_layers(outs["classification"]), _stack_layers(outs["prediction"])
+        bs = reg.shape[0] // layers
+        # the box matching of the LAST decoder layer serves every motion layer (sparse_onedecoder.py:1287)
+        det_index = _tile(self.det_sampler.indices[-bs:], layers)
+        cls_target, cls_weight, best, reg_target, reg_weight, _ = self.motion_sampler.sample(
+            reg, {k: _tile(v, layers) for k, v in gt.items()}, det_index)
+        num_pos = torch.clamp(reduce_mean((det_index >= 0).reshape(layers, -1).sum(dim=1).to(reg.dtype)), min=1.0)
+        cls_loss = self.loss_motion_cls(cls.flatten(end_dim=1), cls_target.flatten(end_dim=1),
+                                        weight=cls_weight.flatten(end_dim=1), avg_factor=num_pos, layers=layers)
+        reg_loss = self.loss_motion_reg(best.flatten(end_dim=1).cumsum(dim=-2), reg_target.flatten(end_dim=1).cumsum(dim=-2),
+                                        weight=reg_weight.flatten(end_dim=1).unsqueeze(-1), avg_factor=num_pos, layers=layers)
         output = {}
-        det_index = self.det_sampler.indices  # matching of the LAST decoder layer, for every motion layer
-        for layer, (cls, reg) in enumerate(zip(outs["classification"], outs["prediction"])):
-            cls_target, cls_weight, best, reg_target, reg_weight, num_pos = self.motion_sampler.sample(reg, gt, det_index)
-            num_pos = torch.clamp(reduce_mean(num_pos), min=1.0)
-            cls_loss = self.loss_motion_cls(cls.flatten(end_dim=1), cls_target.flatten(end_dim=1),
-                                            weight=cls_weight.flatten(end_dim=1), avg_factor=num_pos)
-            reg_loss = self.loss_motion_reg(best.flatten(end_dim=1).cumsum(dim=-2), reg_target.flatten(end_dim=1).cumsum(dim=-2),
-                                            weight=reg_weight.flatten(end_dim=1).unsqueeze(-1), avg_factor=num_pos)
-            self._add(output, "motion_loss_cls", layer, cls_loss)
-            self._add(output, "motion_loss_reg", layer, reg_loss)
+        self._add(output, "motion_loss_cls", cls_loss.reshape(layers))
+        self._add(output, "motion_loss_reg", reg_loss.reshape(layers))
         return output
 
     # ---- planning ---------------------------------------------------------------------------------
@@ -495,48 +524,51 @@ class DecoderLoss:
         key = "fut" if kind[0] in ("temp", "speed") else "spat"
         return data[f"gt_ego_{key}_trajs_{kind[1]}"], data[f"gt_ego_{key}_masks_{kind[1]}"]
 
-    def _plan_terms(self, cls, target, cls_weight, best, gt_target, gt_mask):
-        cls_loss = self.loss_plan_cls(cls.flatten(end_dim=1), target.flatten(end_dim=1), weight=cls_weight.flatten(end_dim=1))
+    def _plan_terms(self, cls, target, cls_weight, best, gt_target, gt_mask, layers):
+        cls_loss = self.loss_plan_cls(cls.flatten(end_dim=1), target.flatten(end_dim=1), weight=cls_weight.flatten(end_dim=1),
+                                      layers=layers)
         reg_loss = self.loss_plan_reg(best.cumsum(dim=-2).flatten(end_dim=1), gt_target.cumsum(dim=-2).flatten(end_dim=1),
-                                      weight=gt_mask.flatten(end_dim=1).unsqueeze(-1))
-        return cls_loss, reg_loss
+                                      weight=gt_mask.flatten(end_dim=1).unsqueeze(-1), layers=layers)
+        return cls_loss.reshape(layers), reg_loss.reshape(layers)
 
     def loss_plan(self, outs, data):
-        output = {}
+        layers = len(outs["classification"])
+        cls, reg = _stack_layers(outs["classification"]), _stack_layers(outs["prediction"])
+        data = {k: (_tile(v, layers) if k.startswith("gt_ego_") else v) for k, v in data.items()}
         kinds = []
         for t in self.plan_anchor_types:
             if t[0] not in kinds:
                 kinds.append(t[0])
-        for layer, (cls, reg) in enumerate(zip(outs["classification"], outs["prediction"])):
-            total = {k: [0.0, 0.0] for k in ("temp", "spat", "speed")}
-            ref_cls, ref_reg = self._plan_slice(cls, reg, self.plan_anchor_refer)
-            ref_gt, ref_mask = self._plan_gt(data, self.plan_anchor_refer)
-            # the winning mode of the reference group decides the target mode of every other group
-            _, ref_target, ref_weight, _, _, _ = self.plan_sampler.sample(ref_cls, ref_reg, ref_gt, ref_mask, data)
-            speed = {}
-            for kind in self.plan_anchor_types:
-                p_cls, p_reg = self._plan_slice(cls, reg, kind)
-                g_traj, g_mask = self._plan_gt(data, kind)
-                if kind[0] in ("temp", "spat"):
-                    a_cls, _, _, best, g_t, g_m = self.align_sampler.sample(p_cls, p_reg, g_traj, g_mask, data, ref_target)
-                    c, r = self._plan_terms(a_cls, ref_target, ref_weight, best, g_t, g_m)
-                    total[kind[0]][0] = total[kind[0]][0] + c
-                    total[kind[0]][1] = total[kind[0]][1] + r
-                elif kind[0] == "speed":
-                    grp = speed.setdefault(kind[1], dict(cls=[], reg=[], gt=(g_traj, g_mask), areas=[]))
-                    grp["cls"].append(p_cls); grp["reg"].append(p_reg); grp["areas"].append(kind[2])
-                else:
-                    raise NotImplementedError(kind)
-            for grp in speed.values():
-                c, r = self._speed_terms(grp, ref_target, data)
-                total["speed"][0] = total["speed"][0] + c
-                total["speed"][1] = total["speed"][1] + r
-            for k in kinds:
-                self._add(output, f"plan_loss_{k}_cls", layer, total[k][0])
-                self._add(output, f"plan_loss_{k}_reg", layer, total[k][1])
+        total = {k: [0.0, 0.0] for k in ("temp", "spat", "speed")}
+        ref_cls, ref_reg = self._plan_slice(cls, reg, self.plan_anchor_refer)
+        ref_gt, ref_mask = self._plan_gt(data, self.plan_anchor_refer)
+        # the winning mode of the reference group decides the target mode of every other group
+        _, ref_target, ref_weight, _, _, _ = self.plan_sampler.sample(ref_cls, ref_reg, ref_gt, ref_mask, data)
+        speed = {}
+        for kind in self.plan_anchor_types:
+            p_cls, p_reg = self._plan_slice(cls, reg, kind)
+            g_traj, g_mask = self._plan_gt(data, kind)
+            if kind[0] in ("temp", "spat"):
+                a_cls, _, _, best, g_t, g_m = self.align_sampler.sample(p_cls, p_reg, g_traj, g_mask, data, ref_target)
+                c, r = self._plan_terms(a_cls, ref_target, ref_weight, best, g_t, g_m, layers)
+                total[kind[0]][0] = total[kind[0]][0] + c
+                total[kind[0]][1] = total[kind[0]][1] + r
+            elif kind[0] == "speed":
+                grp = speed.setdefault(kind[1], dict(cls=[], reg=[], gt=(g_traj, g_mask), areas=[]))
+                grp["cls"].append(p_cls); grp["reg"].append(p_reg); grp["areas"].append(kind[2])
+            else:
+                raise NotImplementedError(kind)
+        for grp in speed.values():
+            c, r = self._speed_terms(grp, ref_target, data, layers)
+            total["speed"][0] = total["speed"][0] + c
+            total["speed"][1] = total["speed"][1] + r
+        output = {}
+        for k in kinds:
+            self._add(output, f"plan_loss_{k}_cls", total[k][0])
+            self._add(output, f"plan_loss_{k}_reg", total[k][1])
         return output
 
-    def _speed_terms(self, grp, ref_target, data):
+    def _speed_terms(self, grp, ref_target, data, layers):
         """Speed groups (reference :1371-1443): every speed bucket contributes the logit and the trajectory of the
         reference mode; the bucket of the ground-truth average speed is the class target."""
         g_traj, g_mask = grp["gt"]
@@ -563,4 +595,4 @@ class DecoderLoss:
         else:
             cls_k, reg_k = cls_k[:, 0], reg_k[:, 0]
         return self._plan_terms(cls_k, bucket, sp_mask.any(dim=-1), _take_mode(reg_k, bucket),
-                                g_traj.unsqueeze(1), g_mask.unsqueeze(1))
+                                g_traj.unsqueeze(1), g_mask.unsqueeze(1), layers)
