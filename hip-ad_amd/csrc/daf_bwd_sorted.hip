@@ -55,7 +55,7 @@ template <bool PLACE>
 __global__ __launch_bounds__(kTapBlock) void daf_tap_pass_kernel(
     int *__restrict__ counter /* cnt (count pass) or cursor (place pass) */, int *__restrict__ taps,
     const int *__restrict__ ss, const int *__restrict__ start, const float *__restrict__ loc,
-    int npair, int cams, int num_feat, int L, int PA /* P*cams*A */) {
+    int npair, int cams, int num_feat, int L, int PA /* P*cams*A */, int cap /* slots in taps[] */) {
   __shared__ int tab[kLdsRows];
   __shared__ int map_base[kMaxMaps];  // LDS slot of the map's first row, or -1
   __shared__ int used_s;
@@ -110,7 +110,9 @@ __global__ __launch_bounds__(kTapBlock) void daf_tap_pass_kernel(
             atomicAdd(&tab[lbase + rel], 1);
           } else {
             const int pos = atomicAdd(counter + gbase + rel, 1);
-            if (PLACE) taps[pos] = id0 | corner;
+            // pos < cap always holds for a consistent workspace; the check keeps a corrupted one (e.g. two
+            // launches sharing it from different streams) from turning into a wild store
+            if (PLACE && (unsigned)pos < (unsigned)cap) taps[pos] = id0 | corner;
           }
         }
       }
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(kTapBlock) void daf_tap_pass_kernel(
         if (in_h && in_w) {
           const int rel = (t.h_low + (corner >> 1)) * W + (t.w_low + (corner & 1));
           const int pos = atomicAdd(&tab[lbase + rel], 1);
-          taps[pos] = id0 | corner;
+          if ((unsigned)pos < (unsigned)cap) taps[pos] = id0 | corner;
         }
       }
     }
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256) void daf_bwd_feat_kernel(
   __shared__ float wc_s[4][kWave][8];
   const int lane = threadIdx.x & (kWave - 1);
   const int wv = threadIdx.x >> 6;
-  const int total = *total_p;
+  const int total = min(max(*total_p, 0), npairL * 4);  // never past the tap buffer, whatever the counter says
   const int nbatch = (total + kWave - 1) / kWave;
   const int nwaves = gridDim.x * 4;
   const int g = lane >> 3;  // group of this lane's 4 channels
@@ -469,12 +471,13 @@ int daf_bwd_sorted_feat(const float *, const int *ss, const int *start, const fl
   const int npair = d.bs * d.A * d.P * d.cams;
   if (fill_zero(w.cnt, (size_t)(R + 1) * 4, stream) != HIPAD_OK) return HIPAD_ELAUNCH;
   const dim3 pg((npair + kTapBlock - 1) / kTapBlock), pb(kTapBlock);
+  const int cap = npair * d.L * 4;
   hipLaunchKernelGGL(daf_tap_pass_kernel<false>, pg, pb, 0, stream, w.cnt, (int *)nullptr, ss, start, loc,
-                     npair, d.cams, d.num_feat, d.L, d.P * d.cams * d.A);
+                     npair, d.cams, d.num_feat, d.L, d.P * d.cams * d.A, cap);
   hipLaunchKernelGGL(daf_alloc_kernel, dim3((R + 1023) / 1024), dim3(1024), 0, stream, w.cnt, w.offs,
                      w.cursor, R);
   hipLaunchKernelGGL(daf_tap_pass_kernel<true>, pg, pb, 0, stream, w.cursor, w.taps, ss, start, loc, npair,
-                     d.cams, d.num_feat, d.L, d.P * d.cams * d.A);
+                     d.cams, d.num_feat, d.L, d.P * d.cams * d.A, cap);
   // persistent grid: 2048 blocks x 4 waves walk the batches of 64 taps
   const long long tmax = (long long)npair * d.L * 4;
   long long nb = (tmax + 255) / 256;

@@ -105,8 +105,9 @@ _ws_cache = {}
 
 
 def _workspace(nbytes, device):
-    """Grow-only per-device scratch (allocated outside any timed/captured region on first use)."""
-    key = device.index
+    """Grow-only scratch per (device, stream): calls on one stream are serialised and may share it, calls issued
+    on different streams (the decoder runs its modality branches concurrently) must not."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)

@@ -64,18 +64,22 @@ class _FeatureGradSink(Function):
     @staticmethod
     def forward(ctx, feat):
         out = feat.view_as(feat)
-        ctx.holder = holder = {"buf": None}
+        ctx.holder = holder = {"bufs": {}}  # one accumulation buffer per stream that runs aggregation backwards
         out._hipad_grad_holder = holder
         token = torch.zeros((), dtype=feat.dtype, device=feat.device)
         return out, token
 
     @staticmethod
     def backward(ctx, grad_feat, grad_token):
-        buf = ctx.holder["buf"]
-        ctx.holder["buf"] = None
-        if buf is None:
-            return grad_feat
-        return buf if grad_feat is None else buf + grad_feat
+        bufs = list(ctx.holder["bufs"].values())
+        ctx.holder["bufs"] = {}
+        total = grad_feat
+        here = torch.cuda.current_stream(grad_token.device) if grad_token.is_cuda else None
+        for buf in bufs:  # the token edges made the engine order this node after every producer stream
+            if here is not None:
+                buf.record_stream(here)
+            total = buf if total is None else total + buf
+        return total
 
 
 def shared_feature_grad(feat):
@@ -117,10 +121,13 @@ class DeformableAggregationFunction(Function):
         grad_feat = ret_feat = None
         grad_token = None
         if ctx.holder is not None:
-            # shared sink: every call site adds into the same buffer; the sink node returns it
-            if ctx.holder["buf"] is None:
-                ctx.holder["buf"] = torch.zeros_like(feat)
-            grad_feat = ctx.holder["buf"]
+            # shared sink: every call site running on THIS stream adds into the same buffer (calls on one stream
+            # are serialised; concurrent streams get a buffer each: the kernel's read-modify-write of rows is
+            # exclusive only within a launch); the sink node sums the buffers
+            key = torch.cuda.current_stream(feat.device).cuda_stream
+            grad_feat = ctx.holder["bufs"].get(key)
+            if grad_feat is None:
+                grad_feat = ctx.holder["bufs"][key] = torch.zeros_like(feat)
             grad_token = torch.zeros((), dtype=feat.dtype, device=feat.device)
         elif need_feat:
             grad_feat = ret_feat = torch.zeros_like(feat)
