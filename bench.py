@@ -57,7 +57,11 @@ def parse():
 
 def dist_setup(n):
     from hipad_amd import dist as D
-    rank, world, local = D.init_from_env("nccl")
+    # RCCL ("nccl") over xGMI.  HIPAD_DIST_BACKEND=gloo + HIPAD_SHARE_GPU=1 rehearse the N > 1 control flow with
+    # several ranks on ONE card (RCCL refuses two ranks per device); never the measured configuration.
+    rank, world, local = D.init_from_env(os.environ.get("HIPAD_DIST_BACKEND", "nccl"))
+    if os.environ.get("HIPAD_SHARE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     return rank, world, local
 
@@ -310,6 +314,10 @@ def main():
     dt = max_over_ranks(time.perf_counter() - t0, dev)
 
     sanity = wl.sanity() if full else None
+    # eager extras run on EVERY rank: the loss path all-reduces its positive counts (reduce_mean), so a rank-0-only
+    # call would leave the other ranks out of a collective
+    loss_terms = wl.loss_terms() if full else None
+    eager_breakdown = wl.breakdown() if (full and a.eager) else None
     if sanity is not None and not sanity["finite"]:
         raise SystemExit(f"bench: the training step went non-finite ({sanity}); refusing to report a throughput")
     daf = wl.daf if full else wl
@@ -323,8 +331,7 @@ def main():
         dtype = "bf16"
         cfg = dict(workload=workload, frames_per_gpu_per_step=a.bs, plan_queries=a.plan_queries, parallelism=f"dp{world}",
                    launch="eager" if a.eager else "hipGraph replay (fwd+bwd graph, eager RCCL all-reduce, clip+AdamW graph)",
-                   eager_frame_breakdown_ms=wl.breakdown() if (rank == 0 and a.eager) else None,
-                   last_step=sanity, loss_terms=wl.loss_terms() if rank == 0 else None,
+                   eager_frame_breakdown_ms=eager_breakdown, last_step=sanity, loss_terms=loss_terms,
                    roofline_scope="dominant hand-written kernel (deformable aggregation); encoder convolutions and "
                                   "GEMMs are MIOpen / hipBLASLt library calls")
     else:
