@@ -117,23 +117,29 @@ __device__ __forceinline__ void online_merge(float &m, float &s, float m2, float
   m = mn;
 }
 
-__global__ __launch_bounds__(256) void weights_softmax_fwd_kernel(
+// Work decomposition (both directions): one workgroup per (b, anchor); T = 256 threads, or 1024 when the
+// anchor has >= 4096 logits (the map head: 100 anchors x 57 600 weights would otherwise sit on 100 x 4 waves).
+// T is a multiple of G, so a thread meets one group g = tid % G in both index orders used below:
+//   j-order  j = (l*P + p)*G + g            the layout of u / v / grad_u   (coalesced reads of u, v)
+//   o-order  o = ((p*cams + cam)*L + l)*G + g   the op layout of weights   (coalesced writes / reads of w)
+template <int T>
+__global__ __launch_bounds__(T) void weights_softmax_fwd_kernel(
     float *__restrict__ w, float *__restrict__ stats, const float *__restrict__ u,
     const float *__restrict__ v, const float *__restrict__ keep, int A, int cams, int L, int P, int G,
     int ucs /* 0: u shared by the cameras, n: u holds per-camera logits [cams, n] */) {
-  __shared__ float red_m[256], red_s[256];
+  __shared__ float red_m[T], red_s[T];
   const int tid = threadIdx.x;
   const long ba = blockIdx.x;  // b*A + a
   const long b = ba / A;
   const int n = L * P * G;
   const float *ua = u + ba * (ucs ? (long)cams * n : (long)n);
   const float *vb = v ? v + b * cams * n : nullptr;
-  // pass 1: online max / sum over this thread's (cam, j) entries, j = tid + 256*k (same g for all)
+  // pass 1 (j-order): online max / sum over this thread's (cam, j) entries
   float m = -INFINITY, s = 0.f;
   for (int cam = 0; cam < cams; ++cam) {
     const float *vc = vb ? vb + (long)cam * n : nullptr;
     const float *uc = ua + (long)cam * ucs;
-    for (int j = tid; j < n; j += 256) {
+    for (int j = tid; j < n; j += T) {
       const float x = uc[j] + (vc ? vc[j] : 0.f);
       if (x > m) {
         s = s * __expf(m - x) + 1.f;
@@ -146,8 +152,7 @@ __global__ __launch_bounds__(256) void weights_softmax_fwd_kernel(
   red_m[tid] = m;
   red_s[tid] = s;
   __syncthreads();
-  // combine the 256/G threads that share a group: tree over tid / G
-  for (int stride = 128; stride >= G; stride >>= 1) {
+  for (int stride = T / 2; stride >= G; stride >>= 1) {
     if (tid < stride) {
       float mm = red_m[tid], sm = red_s[tid];
       online_merge(mm, sm, red_m[tid + stride], red_s[tid + stride]);
@@ -163,27 +168,31 @@ __global__ __launch_bounds__(256) void weights_softmax_fwd_kernel(
     stats[(ba * G + tid) * 2 + 1] = gs;
   }
   const float inv = 1.f / gs;
-  // pass 2: write the weights in the op layout ((p*cams + cam)*L + l)*G + g
+  // pass 2 (o-order): consecutive threads write consecutive weights; u / v are gathered (32-byte runs, L1/L2)
   float *wa = w + ba * (long)cams * n;
-  for (int cam = 0; cam < cams; ++cam) {
-    const float *vc = vb ? vb + (long)cam * n : nullptr;
-    const float *uc = ua + (long)cam * ucs;
-    const float *kc = keep ? keep + (ba * cams + cam) * P : nullptr;
-    for (int j = tid; j < n; j += 256) {
-      const int lp = j / G;  // l*P + p
-      const int l = lp / P, p = lp - l * P;
-      float val = __expf(uc[j] + (vc ? vc[j] : 0.f) - gm) * inv;
-      if (kc) val *= kc[p];
-      wa[(((long)p * cams + cam) * L + l) * G + g] = val;
-    }
+  const int LG = L * G, CLG = cams * LG;
+  for (int o = tid; o < cams * n; o += T) {
+    const int p = o / CLG;
+    const int r = o - p * CLG;
+    const int cam = r / LG;
+    const int lg = r - cam * LG;           // l*G + g
+    const int l = lg / G;
+    const int j = (l * P + p) * G + g;
+    float val = __expf(ua[(long)cam * ucs + j] + (vb ? vb[(long)cam * n + j] : 0.f) - gm) * inv;
+    if (keep) val *= keep[(ba * cams + cam) * P + p];
+    wa[o] = val;
   }
 }
 
-__global__ __launch_bounds__(256) void weights_softmax_bwd_kernel(
-    float *__restrict__ gu, float *__restrict__ gv, const float *__restrict__ gw,
+// backward: grad_x[a, cam, j] = softmax * (grad_w * keep - dot[a, g]);  grad_u = grad_x (per camera) or its sum over
+// the cameras; the camera part grad_v[b, cam, j] = sum over anchors is NOT accumulated here with A-way contended
+// atomics: grad_x is written to `gx_tmp` [bs*A, cams, n] (coalesced) and summed over the anchors by colsum_kernel.
+template <int T>
+__global__ __launch_bounds__(T) void weights_softmax_bwd_kernel(
+    float *__restrict__ gu, float *__restrict__ gx_tmp, const float *__restrict__ gw,
     const float *__restrict__ stats, const float *__restrict__ u, const float *__restrict__ v,
     const float *__restrict__ keep, int A, int cams, int L, int P, int G, int ucs) {
-  __shared__ float red[256];
+  __shared__ float red[T];
   const int tid = threadIdx.x;
   const long ba = blockIdx.x;
   const long b = ba / A;
@@ -194,44 +203,65 @@ __global__ __launch_bounds__(256) void weights_softmax_bwd_kernel(
   const int g = tid % G;
   const float gm = stats[(ba * G + g) * 2 + 0];
   const float inv = 1.f / stats[(ba * G + g) * 2 + 1];
-  // dot[g] = sum over the softmax set of (d w) * softmax
+  const int LG = L * G, CLG = cams * LG;
+  // dot[g] = sum over the softmax set of (d w) * softmax   (o-order: coalesced reads of grad_w)
   float dot = 0.f;
-  for (int cam = 0; cam < cams; ++cam) {
-    const float *vc = vb ? vb + (long)cam * n : nullptr;
-    const float *uc = ua + (long)cam * ucs;
-    const float *kc = keep ? keep + (ba * cams + cam) * P : nullptr;
-    for (int j = tid; j < n; j += 256) {
-      const int lp = j / G;
-      const int l = lp / P, p = lp - l * P;
-      float gy = gwa[(((long)p * cams + cam) * L + l) * G + g];
-      if (kc) gy *= kc[p];
-      dot += gy * __expf(uc[j] + (vc ? vc[j] : 0.f) - gm) * inv;
-    }
+  for (int o = tid; o < cams * n; o += T) {
+    const int p = o / CLG;
+    const int r = o - p * CLG;
+    const int cam = r / LG;
+    const int lg = r - cam * LG;
+    const int l = lg / G;
+    const int j = (l * P + p) * G + g;
+    float gy = gwa[o];
+    if (keep) gy *= keep[(ba * cams + cam) * P + p];
+    dot += gy * __expf(ua[(long)cam * ucs + j] + (vb ? vb[(long)cam * n + j] : 0.f) - gm) * inv;
   }
   red[tid] = dot;
   __syncthreads();
-  for (int stride = 128; stride >= G; stride >>= 1) {
+  for (int stride = T / 2; stride >= G; stride >>= 1) {
     if (tid < stride) red[tid] += red[tid + stride];
     __syncthreads();
   }
   const float gdot = red[g];
+  // j-order: coalesced writes of grad_u / gx_tmp; grad_w gathered in 32-byte runs
   float *gua = gu + ba * (ucs ? (long)cams * n : (long)n);
-  float *gvb = gv ? gv + b * cams * n : nullptr;
-  for (int j = tid; j < n; j += 256) {
+  float *gxa = gx_tmp ? gx_tmp + ba * (long)cams * n : nullptr;
+  for (int j = tid; j < n; j += T) {
     const int lp = j / G;
     const int l = lp / P, p = lp - l * P;
     float acc = 0.f;
     for (int cam = 0; cam < cams; ++cam) {
-      const float *kc = keep ? keep + (ba * cams + cam) * P : nullptr;
       float gy = gwa[(((long)p * cams + cam) * L + l) * G + g];
-      if (kc) gy *= kc[p];
+      if (keep) gy *= keep[(ba * cams + cam) * P + p];
       const float sm = __expf(ua[(long)cam * ucs + j] + (vb ? vb[(long)cam * n + j] : 0.f) - gm) * inv;
       const float gx = sm * (gy - gdot);
       if (ucs) gua[(long)cam * ucs + j] = gx; else acc += gx;
-      if (gvb) atomicAdd(gvb + (long)cam * n + j, gx);
+      if (gxa) gxa[(long)cam * n + j] = gx;
     }
     if (!ucs) gua[j] = acc;
   }
+}
+
+// out[b, c] = sum over a of x[b, a, c]: each workgroup sums a slab of `rows_per_block` anchors for 256 columns
+// (coalesced rows) and adds its partial with one atomic per column (contention A / rows_per_block).
+__global__ __launch_bounds__(256) void colsum_kernel(float *__restrict__ out, const float *__restrict__ x, int A,
+                                                     long cols, int rows_per_block) {
+  const long c = (long)blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.z;
+  const int a0 = blockIdx.y * rows_per_block, a1 = min(A, a0 + rows_per_block);
+  if (c >= cols) return;
+  const float *xb = x + ((long)b * A) * cols + c;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int a = a0;
+  for (; a + 3 < a1; a += 4) {
+    s0 += xb[(long)a * cols];
+    s1 += xb[(long)(a + 1) * cols];
+    s2 += xb[(long)(a + 2) * cols];
+    s3 += xb[(long)(a + 3) * cols];
+  }
+  for (; a < a1; ++a) s0 += xb[(long)a * cols];
+  atomicAdd(out + (long)b * cols + c, (s0 + s1) + (s2 + s3));
 }
 
 }  // namespace hipad
@@ -268,22 +298,51 @@ int hipad_weights_softmax_forward(float *weights, float *stats, const float *u, 
                                   int u_per_cam, hipad_stream_t stream) {
   if (!weights || !stats || !u) return HIPAD_EINVAL;
   if (bs <= 0 || A <= 0 || cams <= 0 || L <= 0 || P <= 0 || G <= 0 || 256 % G) return HIPAD_EINVAL;
-  hipLaunchKernelGGL(weights_softmax_fwd_kernel, dim3((unsigned)(bs * A)), dim3(256), 0, (hipStream_t)stream,
-                     weights, stats, u, v, keep, A, cams, L, P, G, u_per_cam ? L * P * G : 0);
+  const int n = L * P * G;
+  if (n >= 4096 && 1024 % G == 0)
+    hipLaunchKernelGGL(weights_softmax_fwd_kernel<1024>, dim3((unsigned)(bs * A)), dim3(1024), 0, (hipStream_t)stream,
+                       weights, stats, u, v, keep, A, cams, L, P, G, u_per_cam ? n : 0);
+  else
+    hipLaunchKernelGGL(weights_softmax_fwd_kernel<256>, dim3((unsigned)(bs * A)), dim3(256), 0, (hipStream_t)stream,
+                       weights, stats, u, v, keep, A, cams, L, P, G, u_per_cam ? n : 0);
   return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
+}
+
+size_t hipad_weights_softmax_backward_workspace(int bs, int A, int cams, int L, int P, int G, int has_v) {
+  return has_v ? (size_t)bs * A * cams * L * P * G * sizeof(float) : 0;
 }
 
 int hipad_weights_softmax_backward(float *grad_u, float *grad_v, const float *grad_weights,
                                    const float *stats, const float *u, const float *v, const float *keep,
                                    int bs, int A, int cams, int L, int P, int G, int u_per_cam,
-                                   hipad_stream_t stream) {
+                                   void *workspace, size_t workspace_bytes, hipad_stream_t stream_) {
   if (!grad_u || !grad_weights || !stats || !u || (v && !grad_v)) return HIPAD_EINVAL;
   if (bs <= 0 || A <= 0 || cams <= 0 || L <= 0 || P <= 0 || G <= 0 || 256 % G) return HIPAD_EINVAL;
-  if (grad_v && fill_zero(grad_v, (size_t)bs * cams * L * P * G * sizeof(float), (hipStream_t)stream) != HIPAD_OK)
-    return HIPAD_ELAUNCH;
-  hipLaunchKernelGGL(weights_softmax_bwd_kernel, dim3((unsigned)(bs * A)), dim3(256), 0, (hipStream_t)stream,
-                     grad_u, v ? grad_v : nullptr, grad_weights, stats, u, v, keep, A, cams, L, P, G,
-                     u_per_cam ? L * P * G : 0);
+  hipStream_t stream = (hipStream_t)stream_;
+  const int n = L * P * G;
+  float *gx_tmp = nullptr;
+  if (v) {
+    if (!workspace || workspace_bytes < hipad_weights_softmax_backward_workspace(bs, A, cams, L, P, G, 1))
+      return HIPAD_EWORKSPACE;
+    gx_tmp = (float *)workspace;
+    if (fill_zero(grad_v, (size_t)bs * cams * n * sizeof(float), stream) != HIPAD_OK) return HIPAD_ELAUNCH;
+  }
+  if (n >= 4096 && 1024 % G == 0)
+    hipLaunchKernelGGL(weights_softmax_bwd_kernel<1024>, dim3((unsigned)(bs * A)), dim3(1024), 0, stream, grad_u, gx_tmp,
+                       grad_weights, stats, u, v, keep, A, cams, L, P, G, u_per_cam ? n : 0);
+  else
+    hipLaunchKernelGGL(weights_softmax_bwd_kernel<256>, dim3((unsigned)(bs * A)), dim3(256), 0, stream, grad_u, gx_tmp,
+                       grad_weights, stats, u, v, keep, A, cams, L, P, G, u_per_cam ? n : 0);
+  if (v) {
+    const long cols = (long)cams * n;
+    // enough workgroups to cover the chip: slabs of anchors when there are few columns
+    int slabs = (int)((2048 * 256 + cols - 1) / cols);
+    if (slabs > A) slabs = A;
+    if (slabs < 1) slabs = 1;
+    const int rpb = (A + slabs - 1) / slabs;
+    const dim3 grid((unsigned)((cols + 255) / 256), (unsigned)((A + rpb - 1) / rpb), (unsigned)bs);
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, stream, grad_v, (const float *)gx_tmp, A, cols, rpb);
+  }
   return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
 }
 

@@ -26,7 +26,8 @@ SIGNATURES = {
     "hipad_project_points_forward": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "hipad_project_points_backward": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "hipad_weights_softmax_forward": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
-    "hipad_weights_softmax_backward": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p]),
+    "hipad_weights_softmax_backward_workspace": (c_size_t, [c_int] * 7),
+    "hipad_weights_softmax_backward": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p, c_size_t, c_void_p]),
     "hipad_linear_forward": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "hipad_linear_backward": (c_int, [c_void_p] * 7 + [c_int] * 3 + [c_void_p]),
     "hipad_layernorm_forward": (c_int, [c_void_p] * 6 + [c_int, c_int, ctypes.c_float, c_void_p]),
@@ -241,10 +242,13 @@ def weights_softmax_backward(grad_w, stats, u, v, keep, L, P, G):
     cams = u.shape[2] if per_cam else v.shape[1]
     gu = torch.empty_like(u)
     gv = torch.empty_like(v) if v is not None else None
+    nbytes = lib.hipad_weights_softmax_backward_workspace(bs, A, cams, L, P, G, int(v is not None))
+    ws = _workspace(nbytes, u.device) if nbytes else None
     with torch.cuda.device(u.device):
         st = lib.hipad_weights_softmax_backward(gu.data_ptr(), _ptr(gv), grad_w.data_ptr(), stats.data_ptr(),
                                                 u.data_ptr(), _ptr(v), _ptr(keep), bs, A, cams, L, P, G,
-                                                int(per_cam), stream_ptr(u.device))
+                                                int(per_cam), _ptr(ws), ws.numel() if ws is not None else 0,
+                                                stream_ptr(u.device))
     check(st, "hipad_weights_softmax_backward")
     return gu, gv
 

@@ -152,11 +152,15 @@ int hipad_weights_softmax_forward(float *weights, float *stats, const float *u, 
                                   const float *keep, int batch_size, int num_anchors, int num_cams,
                                   int num_scale, int num_pts, int num_groups, int u_per_cam,
                                   hipad_stream_t stream);
+/* backward scratch (bytes): the per-(anchor, camera) logit gradients before they are summed over the anchors
+ * into grad_v; 0 when there is no camera part (has_v == 0) */
+size_t hipad_weights_softmax_backward_workspace(int batch_size, int num_anchors, int num_cams, int num_scale,
+                                                int num_pts, int num_groups, int has_v);
 int hipad_weights_softmax_backward(float *grad_u, float *grad_v, const float *grad_weights,
                                    const float *stats, const float *u, const float *v,
                                    const float *keep, int batch_size, int num_anchors, int num_cams,
                                    int num_scale, int num_pts, int num_groups, int u_per_cam,
-                                   hipad_stream_t stream);
+                                   void *workspace, size_t workspace_bytes, hipad_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Multi-head attention core: out = dropout(softmax(q k^T * softmax_scale)) v per (batch, head).
