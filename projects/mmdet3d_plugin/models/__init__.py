@@ -1,7 +1,7 @@
 """Model-side mirror of the reference plugin for the hot path."""
 from .attention import FlashMHA, MultiheadFlashAttention, gen_sineembed_for_position  # noqa: F401
 from .blocks import AsymmetricFFN, CustomOperation, DeformableFeatureAggregation, DenseDepthNet  # noqa: F401
-from . import criterion  # noqa: F401  registers the loss / sampler classes
+from . import criterion, decode  # noqa: F401  register the loss / sampler / result-decoder classes
 from .det import *  # noqa: F401,F403
 from .ego import *  # noqa: F401,F403
 from .grid_mask import GridMask  # noqa: F401

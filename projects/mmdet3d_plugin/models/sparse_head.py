@@ -30,4 +30,18 @@ class SparseHead(BaseModule):
         return self.onedecoder_head.loss(*model_outs, data)
 
     def post_process(self, model_outs, data):
-        return self.onedecoder_head.post_process(*model_outs, data)
+        """One result dict per sample with the entries of every selected task (reference sparse_head.py:108-154).
+        (The reference builds ``[dict()] * batch_size`` -- one dict shared by all samples; a dict per sample here.)"""
+        det_output, map_output, ego_output, plan_output, motion_output, _ = model_outs
+        per_task = dict(zip(("det", "map", "ego", "plan", "motion"),
+                            self.onedecoder_head.post_process(det_output, map_output, ego_output, plan_output,
+                                                              motion_output, data)))
+        first = next(per_task[t] for t in self.onedecoder_head.task_select if per_task.get(t) is not None)
+        results = [dict() for _ in range(len(first))]
+        for i, res in enumerate(results):
+            for task in self.onedecoder_head.task_select:
+                if per_task.get(task) is not None:
+                    res.update(per_task[task][i])
+        if self.evaluate_bench2dive:
+            raise NotImplementedError("the open-loop planning metric (evaluate_bench2dive) is outside the hot path")
+        return results

@@ -484,5 +484,20 @@ class SparseOneDecoder(DecoderLoss, BaseModule):
     # ------------------------------------------------------------------------------------
     # loss(): DecoderLoss (criterion.py) -- target assignment and every loss term on the device
 
-    def post_process(self, *args, **kwargs):
-        raise NotImplementedError("result decoding (reference sparse_onedecoder.py:1581-1605) is a 'next' row (8f/3)")
+    def post_process(self, det_output, map_output, ego_output, plan_output, motion_output, data, output_idx=-1):
+        """Per-task result decoding (reference sparse_onedecoder.py:1581-1605)."""
+        det = mp = ego = plan = motion = None
+        if "det" in self.task_select:
+            det = self.det_decoder.decode(det_output["classification"], det_output["prediction"],
+                                          det_output.get("instance_id"), det_output.get("quality"), output_idx=output_idx)
+        if "map" in self.task_select:
+            mp = self.map_decoder.decode(map_output["classification"], map_output["prediction"],
+                                         map_output.get("instance_id"), map_output.get("quality"), output_idx=output_idx)
+        if "motion" in self.task_select:
+            motion = self.motion_decoder.decode(det_output["classification"], det_output["prediction"],
+                                                det_output.get("instance_id"), det_output.get("quality"), motion_output)
+        if "ego" in self.task_select and not self.with_supervise_ego_status:
+            raise NotImplementedError("ego trajectory decoding is unused by the HiP-AD configs")
+        if "plan" in self.task_select:
+            plan = self.plan_decoder.decode(ego_output, det_output, motion_output, plan_output, data)
+        return det, mp, ego, plan, motion

@@ -250,6 +250,7 @@ def install():
          build_loss=lambda cfg: build_from_cfg(cfg, LOSSES))
     _mod("mmdet.models.builder", LOSSES=LOSSES, HEADS=HEADS, DETECTORS=DETECTORS)
     _mod("mmdet.models.losses", l1_loss=ML.l1_loss, smooth_l1_loss=ML.smooth_l1_loss)
+    _mod("cv2")  # datasets/utils.py imports it for drawing helpers the decoders never call
     _mod("flash_attn")
     _mod("flash_attn.flash_attn_interface", flash_attn_unpadded_kvpacked_func=None,
          flash_attn_varlen_kvpacked_func=None)

@@ -73,3 +73,20 @@ def ground_truth():
         data[f"gt_ego_{kind}_masks_{rate}"] = (u(BS, TS) > 0.15).float()
     data["gt_ego_fut_trajs_5hz"][1] *= 0.02   # second sample nearly standing still: lowest speed bucket
     return data
+
+
+def decode_inputs():
+    """Head outputs + data of sample 0 for the result-decoder golden case: the loss case's tensors with a dozen
+    confident, car-sized agents scattered around the ego's candidate paths so that the plan rescoring has
+    collisions to find."""
+    outs = [{k: ([t[:1] if t is not None else None for t in v] if isinstance(v, list) else v) for k, v in o.items()}
+            for o in head_outputs()]
+    det = outs[0]
+    g = torch.Generator().manual_seed(4321)
+    det["classification"][-1][0] -= 3.0        # background queries stay under the rescoring's confidence threshold
+    det["classification"][-1][0, :12] += 9.0   # a dozen confident agents
+    radius, angle = 7.0 + 5.0 * torch.rand(12, generator=g), 2 * math.pi * torch.rand(12, generator=g)
+    det["prediction"][-1][0, :12, :2] = torch.stack([radius * angle.cos(), radius * angle.sin()], dim=-1)
+    det["prediction"][-1][0, :12, 3:6] = torch.log(torch.tensor([2.0, 4.5, 1.6]))
+    data = {k: (v[:1] if isinstance(v, torch.Tensor) else v) for k, v in ground_truth().items()}
+    return outs, data

@@ -418,7 +418,43 @@ def gen_losses():
     save("losses_stage2", **out)
 
 
-GENS = {"losses": gen_losses, "daf": gen_daf, "format": gen_format, "project": gen_project, "dfa": gen_keypoints_and_dfa,
+def gen_decode():
+    """The reference's result decoders (det / map / motion / plan with collision rescoring) through its own
+    SparseOneDecoder.post_process (sparse_onedecoder.py:1581-1605) on the seeded head outputs of loss_case.py,
+    sample 0 only (the plan rescoring is written for batch 1, as in the closed loop)."""
+    import copy
+    import loss_case as LC
+    for m in ("models.det.decoder", "models.map.decoder", "models.motion.decoder", "models.plan.decoder",
+              "models.instance_bank", "models.plan.instance_bank", "models.ego.instance_bank", "models.plan.blocks",
+              "models.ego.blocks", "models.motion.blocks", "models.attention", "models.separate_attn",
+              "models.base_target", "models.det.target", "models.det.losses", "models.map.target", "models.map.match_cost",
+              "models.map.loss", "models.plan.target", "models.motion.target"):
+        S.ref_import(m)
+    ref_dec = S.ref_import("models.sparse_onedecoder")
+    txt = cfg_text().replace('"/opt/data/private/project/HiP-AD"', repr(S.REF))
+    ns = {}
+    exec(compile(txt, "hipad_b2d_stage2.py", "exec"), ns)
+    od = copy.deepcopy(ns["model"]["head"]["onedecoder_head"])
+    dec = object.__new__(ref_dec.SparseOneDecoder)
+    torch.nn.Module.__init__(dec)
+    for k in ("det", "map", "plan", "motion"):
+        setattr(dec, f"{k}_decoder", S.build_from_cfg(od[f"{k}_decoder"], S.BBOX_CODERS))
+    dec.task_select, dec.with_supervise_ego_status = od["task_select"], od["with_supervise_ego_status"]
+    outs, data = LC.decode_inputs()
+    det, mp, ego, plan, motion, _ = outs
+    with torch.no_grad():
+        det_r, map_r, ego_r, plan_r, motion_r = dec.post_process(det, mp, ego, plan, motion, data)
+    out = dict(det_boxes=det_r[0]["boxes_3d"], det_scores=det_r[0]["scores_3d"], det_labels=det_r[0]["labels_3d"],
+               det_cls_scores=det_r[0]["cls_scores"], map_vectors=np.stack(map_r[0]["vectors"]), map_scores=map_r[0]["scores"],
+               map_labels=map_r[0]["labels"], motion_trajs=motion_r[0]["trajs_3d"], motion_scores=motion_r[0]["trajs_score"],
+               plan_keys=np.array(sorted(plan_r[0])))
+    for k, v in plan_r[0].items():
+        out[k] = v
+    print({k: tuple(np.asarray(v).shape) for k, v in out.items()})
+    save("decode_stage2", **out)
+
+
+GENS = {"decode": gen_decode, "losses": gen_losses, "daf": gen_daf, "format": gen_format, "project": gen_project, "dfa": gen_keypoints_and_dfa,
         "decoder": gen_decoder}
 
 if __name__ == "__main__":

@@ -1,0 +1,119 @@
+"""Result decoders (projects/mmdet3d_plugin/models/decode.py) against the reference's own decoders run through its
+SparseOneDecoder.post_process (tests/golden/decode_stage2.npz, make_golden.gen_decode): ranked boxes / scores /
+labels, map vectors, agent trajectories and the six plan outputs incl. the collision-aware rescoring."""
+import numpy as np
+import pytest
+import torch
+
+import loss_case as LC
+
+
+def build_decoder_shell():
+    import projects.mmdet3d_plugin.models  # noqa: F401
+    from hipad_amd.compat import BBOX_CODERS, build_from_cfg
+    from projects.configs._hipad_b2d_common import hipad_b2d
+    from projects.mmdet3d_plugin.models.sparse_onedecoder import SparseOneDecoder
+    od = hipad_b2d(stage=2)["model"]["head"]["onedecoder_head"]
+    dec = object.__new__(SparseOneDecoder)
+    torch.nn.Module.__init__(dec)
+    for k in ("det", "map", "plan", "motion"):
+        setattr(dec, f"{k}_decoder", build_from_cfg(od[f"{k}_decoder"], BBOX_CODERS))
+    dec.task_select, dec.with_supervise_ego_status = od["task_select"], od["with_supervise_ego_status"]
+    return dec
+
+
+def to_device(obj, device):
+    if isinstance(obj, torch.Tensor):
+        return obj.to(device)
+    if isinstance(obj, dict):
+        return {k: to_device(v, device) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [to_device(v, device) for v in obj]
+    return obj
+
+
+def close(a, b, tol=1e-4):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), float(np.abs(a - b).max())
+
+
+def run(device, golden):
+    z = golden("decode_stage2")
+    outs, data = LC.decode_inputs()
+    outs, data = to_device(outs, device), to_device(data, device)
+    dec = build_decoder_shell()
+    with torch.no_grad():
+        det, mp, _, plan, motion = dec.post_process(*outs[:5], data)
+    assert (det[0]["labels_3d"].numpy() == z["det_labels"]).all()
+    close(det[0]["scores_3d"], z["det_scores"]); close(det[0]["cls_scores"], z["det_cls_scores"])
+    close(det[0]["boxes_3d"], z["det_boxes"])
+    assert (mp[0]["labels"] == z["map_labels"]).all()
+    close(mp[0]["scores"], z["map_scores"]); close(np.stack(mp[0]["vectors"]), z["map_vectors"])
+    close(motion[0]["trajs_3d"], z["motion_trajs"]); close(motion[0]["trajs_score"], z["motion_scores"])
+    assert sorted(plan[0]) == z["plan_keys"].tolist()
+    for k in plan[0]:
+        close(plan[0][k], z[k])
+    return dec, outs, data
+
+
+def test_result_decoders_match_reference_cpu(golden):
+    dec, outs, data = run("cpu", golden)
+    # the case really exercises the rescoring: some, but not all, 2 Hz plan modes collide with an agent
+    pd = dec.plan_decoder
+    det, _, _, plan, motion, _ = outs
+    k = pd.anchor_types.index(("temp", "2hz"))
+    cls = plan["classification"][-1].chunk(pd.num_group, dim=2)[k].reshape(1, -1)
+    reg = plan["prediction"][-1].chunk(pd.num_group, dim=2)[k].reshape(1, -1, pd.ego_fut_ts, 2).cumsum(-2)
+    ag = pd._agents(det, motion)
+    rescored, all_col = pd.rescore(cls, reg, ag["motion_cls"], ag["motion_reg"], ag["anchors"], ag["confidence"],
+                                   ego_fut_mode=reg.shape[1])
+    hit = int((rescored < cls - 100).sum())
+    assert 0 < hit < cls.shape[1] and not bool(all_col.any())
+
+
+@pytest.mark.gpu
+def test_result_decoders_match_reference_gpu(golden):
+    run("cuda", golden)
+
+
+def test_head_post_process_merges_tasks_per_sample():
+    from types import SimpleNamespace
+    from projects.mmdet3d_plugin.models.sparse_head import SparseHead
+    head = object.__new__(SparseHead)
+    torch.nn.Module.__init__(head)
+    head.evaluate_bench2dive = False
+    head.onedecoder_head = SimpleNamespace(
+        task_select=["det", "plan"],
+        post_process=lambda *a: ([dict(a=1), dict(a=2)], None, None, [dict(b=3), dict(b=4)], None))
+    res = head.post_process((None,) * 6, {})
+    assert res == [dict(a=1, b=3), dict(a=2, b=4)] and res[0] is not res[1]
+
+
+@pytest.mark.gpu
+def test_simple_test_end_to_end_three_frames():
+    """Inference entry point of the detector (encoder -> decoder with temporal caches and track ids -> result
+    decoders) on three consecutive synthetic frames: result keys / shapes, finite values, ids persist."""
+    import warnings
+    warnings.filterwarnings("ignore")
+    from hipad_amd.frame import SyntheticFrames, build_detector
+    torch.manual_seed(3)
+    model, _ = build_detector(stage=2, plan_queries=480)
+    model.eval()
+    frames = SyntheticFrames(seed=1)
+    seen = []
+    with torch.no_grad():
+        for _ in range(3):
+            img, data = frames.next()
+            res = model.simple_test(img, **data)
+            assert len(res) == 1 and set(res[0]) == {"img_bbox"}
+            r = res[0]["img_bbox"]
+            for key in ("boxes_3d", "scores_3d", "labels_3d", "cls_scores", "instance_ids", "vectors", "scores", "labels",
+                        "trajs_3d", "trajs_score", "plan_temp_5hz", "plan_spat_2m", "plan_temp_2hz", "plan_spat_5m",
+                        "plan_speed_5hz", "plan_speed_2hz"):
+                assert key in r, key
+            assert r["boxes_3d"].shape == (300, 10) and r["trajs_3d"].shape == (300, 6, 6, 2)
+            assert r["plan_spat_2m"].shape == (6, 2) and r["plan_speed_5hz"].shape == (6, 2)
+            assert all(bool(torch.isfinite(r[k]).all()) for k in ("boxes_3d", "scores_3d", "plan_spat_2m", "plan_speed_5hz"))
+            seen.append(r["instance_ids"].cpu())
+    assert int(seen[0].min()) >= 0 and len(set(seen[2].tolist()) & set(seen[1].tolist())) > 0
