@@ -53,6 +53,34 @@ class FlatGrads:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
         self.comm_dtype = comm_dtype
         self._comm = torch.empty(total, dtype=comm_dtype, device=ref.device) if comm_dtype not in (None, ref.dtype) else None
+        self._views = [p.grad for p in self.params]
+        self._loose = []
+
+    # ---- gradients autograd accumulates itself -----------------------------------------------------
+    # With ``p.grad`` preset to a (zeroed) view, autograd's AccumulateGrad runs one ``grad += new`` kernel per
+    # parameter and step: ~500 tiny launches for the parameters no kernel of ours writes in place (BatchNorm,
+    # convolutions, embeddings, Scale ...).  For those, ``p.grad`` is set to None before backward (autograd then
+    # just keeps the incoming tensor: no kernel) and ONE multi-tensor copy moves them into the flat buffer after.
+    def loosen(self, inplace_ids):
+        """Parameters whose id is not in ``inplace_ids`` get the None-then-gather treatment from now on."""
+        self._loose = [(p, v) for p, v in zip(self.params, self._views) if id(p) not in inplace_ids]
+
+    def before_backward(self):
+        for p, _ in self._loose:
+            p.grad = None
+
+    def after_backward(self):
+        if not self._loose:
+            return
+        dst, src = [], []
+        for p, view in self._loose:
+            g = p.grad
+            if g is not None and g.data_ptr() != view.data_ptr():
+                dst.append(view)
+                src.append(g if g.dtype == view.dtype else g.to(view.dtype))
+            p.grad = view
+        if dst:
+            torch._foreach_copy_(dst, src)
 
     def zero(self):
         self.flat.zero_()

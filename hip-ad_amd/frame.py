@@ -113,6 +113,7 @@ class TrainStep:
                              max_norm=self.max_norm, comm_dtype=comm_dtype)
         self.params = self.opt.params
         self.grads = self.opt.grads
+        self._loosened = False
 
     @property
     def grad_norm(self):
@@ -120,8 +121,14 @@ class TrainStep:
         return self.opt.grad_norm
 
     def forward_backward(self, img, data):
+        from . import functional as HF
         loss = _frame_loss(self.model, img, data)
+        self.grads.before_backward()
         loss.backward()
+        self.grads.after_backward()
+        if not self._loosened:  # after the first backward it is known which gradients our kernels write in place
+            self.grads.loosen(HF.INPLACE_PARAMS)
+            self._loosened = True
         return loss
 
     def update(self):
@@ -245,9 +252,7 @@ class GraphedTrainStep:
 
     def _fwd_bwd(self):
         # gradients start at zero: FlatGrads allocates them so and every update() clears them again
-        loss = _frame_loss(self.model, self.img, self.data)
-        loss.backward()
-        return loss
+        return self.inner.forward_backward(self.img, self.data)
 
     def _update(self):
         from . import functional as HF

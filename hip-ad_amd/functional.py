@@ -125,6 +125,10 @@ import os as _os
 LINEAR_MODE = _os.environ.get("HIPAD_LINEAR_MODE", "mfma_bf16")  # "torch_fp32": library fp32 GEMMs (fp32 parity runs)
 LINEAR_INPLACE_GRAD = _os.environ.get("HIPAD_LINEAR_INPLACE_GRAD", "1") == "1"
 LINEAR_BWD = _os.environ.get("HIPAD_LINEAR_BWD", "mfma")  # "torch": debugging aid, backward by library matmuls
+# ids of the parameters whose gradient some kernel here has accumulated IN PLACE into ``param.grad`` (Linear /
+# LayerNorm weights and biases): hipad_amd.dist.FlatGrads uses it to tell them from the parameters autograd
+# accumulates itself (see FlatGrads.loosen)
+INPLACE_PARAMS = set()
 
 
 class linear_mode:
@@ -179,6 +183,7 @@ class _Linear(Function):
             g = weight.grad if LINEAR_INPLACE_GRAD else None
             if g is not None and g.is_contiguous() and g.dtype == torch.float32:
                 dw = g[r0:r1]
+                INPLACE_PARAMS.add(id(weight))
             else:
                 ret_w = torch.zeros_like(weight)
                 dw = ret_w[r0:r1]
@@ -186,6 +191,7 @@ class _Linear(Function):
             g = bias.grad if LINEAR_INPLACE_GRAD else None
             if g is not None and g.is_contiguous() and g.dtype == torch.float32:
                 db = g[r0:r1]
+                INPLACE_PARAMS.add(id(bias))
             else:
                 ret_b = torch.zeros_like(bias)
                 db = ret_b[r0:r1]
@@ -244,12 +250,14 @@ class _LayerNorm(Function):
             g = weight.grad if LINEAR_INPLACE_GRAD else None
             if g is not None and g.is_contiguous() and g.dtype == torch.float32:
                 dgamma = g
+                INPLACE_PARAMS.add(id(weight))
             else:
                 dgamma = ret_w = torch.zeros_like(weight)
         if bias is not None and ctx.needs_input_grad[2]:
             g = bias.grad if LINEAR_INPLACE_GRAD else None
             if g is not None and g.is_contiguous() and g.dtype == torch.float32:
                 dbeta = g
+                INPLACE_PARAMS.add(id(bias))
             else:
                 dbeta = ret_b = torch.zeros_like(bias)
         _lib.layernorm_backward(dy2, x2, mean, rstd, None if weight is None else weight.detach(), dx, dgamma, dbeta)
