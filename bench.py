@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="stage2_full", choices=("stage2_full", "daf_stage2"))
+    ap.add_argument("--workload", default="stage2_full", choices=("stage2_full", "daf_stage2", "stage2_infer"))
     ap.add_argument("--plan-queries", type=int, default=480, choices=(48, 480))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch the step kernel by kernel instead of replaying hipGraphs")
@@ -247,6 +247,24 @@ class Stage2Full:
         return {k: round(v, 3) for k, v in acc.items()}
 
 
+class Stage2Infer:
+    """Closed-loop style inference: one frame per step through the replayed network graph + track ids + result
+    decoders (detections, map vectors, agent trajectories, plan way-points on the host)."""
+
+    def __init__(self, device, seed, plan_queries=480):
+        import warnings
+        warnings.filterwarnings("ignore", category=DeprecationWarning)
+        from hipad_amd.frame import GraphedInference, SyntheticFrames, build_detector
+        torch.manual_seed(1234)
+        self.model, _ = build_detector(stage=2, input_hw=(256, 704), plan_queries=plan_queries, device=device)
+        self.frames = SyntheticFrames(bs=1, input_hw=(256, 704), device=device, seed=seed)
+        self.graphed = GraphedInference(self.model, self.frames)
+        self.daf = DafStage2(device, seed, plan_queries)
+
+    def step(self):
+        self.last = self.graphed()
+
+
 def _daf_grid_threads(A, P, cams=6, bs=1):
     """Threads of the wave-per-item aggregation launches for (A, P): the host-side work split of
     hip-ad_amd/csrc/daf.hip make_plan(), restated to find this launch in the rocprofv3 counter files."""
@@ -295,7 +313,9 @@ def main():
     rank, world, local = dist_setup(a.gpus)
     dev = torch.device("cuda", local)
     full = a.workload == "stage2_full"
+    infer = a.workload == "stage2_infer"
     wl = (Stage2Full(dev, seed=rank, plan_queries=a.plan_queries, bs=a.bs, eager=a.eager) if full
+          else Stage2Infer(dev, seed=rank, plan_queries=a.plan_queries) if infer
           else DafStage2(dev, seed=rank, plan_queries=a.plan_queries))
 
     def barrier():
@@ -320,7 +340,7 @@ def main():
     eager_breakdown = wl.breakdown() if (full and a.eager) else None
     if sanity is not None and not sanity["finite"]:
         raise SystemExit(f"bench: the training step went non-finite ({sanity}); refusing to report a throughput")
-    daf = wl.daf if full else wl
+    daf = wl.daf if (full or infer) else wl
     roof = roofline_of(daf)
     if full:
         workload = ("stage2_full: one training step (forward + the reference's losses with device-side Hungarian target "
@@ -334,6 +354,13 @@ def main():
                    eager_frame_breakdown_ms=eager_breakdown, last_step=sanity, loss_terms=loss_terms,
                    roofline_scope="dominant hand-written kernel (deformable aggregation); encoder convolutions and "
                                   "GEMMs are MIOpen / hipBLASLt library calls")
+    elif infer:
+        workload = ("stage2_infer: closed-loop style inference of hipad_b2d_stage2, batch 1, one 6-cam 704x256 frame per step: "
+                    "encoder + decoder replayed from a hipGraph, then track ids and the result decoders (boxes, map vectors, "
+                    "agent trajectories, plan way-points incl. collision rescoring) with their device->host copies; ms_per_step "
+                    "is the per-frame latency")
+        dtype = "bf16"
+        cfg = dict(workload=workload, frames_per_gpu_per_step=1, plan_queries=a.plan_queries, parallelism=f"dp{world}")
     else:
         workload = ("daf_stage2: the 24 deformable-aggregation calls (6 layers x det 900x13, map 100x300, "
                     f"plan {a.plan_queries}x90, ego 1x13) fwd+bwd of one stage-2 frame, 6 cams 704x256, "

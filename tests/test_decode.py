@@ -117,3 +117,44 @@ def test_simple_test_end_to_end_three_frames():
             assert all(bool(torch.isfinite(r[k]).all()) for k in ("boxes_3d", "scores_3d", "plan_spat_2m", "plan_speed_5hz"))
             seen.append(r["instance_ids"].cpu())
     assert int(seen[0].min()) >= 0 and len(set(seen[2].tolist()) & set(seen[1].tolist())) > 0
+
+
+@pytest.mark.gpu
+def test_graphed_inference_matches_eager_forward():
+    """The replayed inference network writes the head outputs the eager forward produces on the same frame
+    sequence (compared before ranking: with random weights the score order is decided by bf16-level noise)."""
+    import warnings
+    warnings.filterwarnings("ignore")
+    from hipad_amd.frame import GraphedInference, SyntheticFrames, build_detector
+    heads = []
+    for mode in ("eager", "graph"):
+        torch.manual_seed(11)
+        model, _ = build_detector(stage=2, plan_queries=480)
+        model.eval()
+        frames = SyntheticFrames(seed=2)
+        with torch.no_grad():
+            if mode == "eager":
+                model.head.onedecoder_head.with_instance_id = False
+                for _ in range(6):
+                    img, data = frames.next()
+                    outs = model.head(img, model.extract_feat(img, False, data), data)
+            else:
+                step = GraphedInference(model, frames)   # consumes frames 0..4
+                res = step()                              # frame 5
+                outs = step.outs
+                assert set(res[0]["img_bbox"]) >= {"boxes_3d", "instance_ids", "plan_spat_2m", "plan_speed_5hz", "vectors"}
+        det, mp, ego, plan, motion, _ = outs
+        heads.append([det["classification"][-1], det["prediction"][-1], mp["prediction"][-1], plan["classification"][-1],
+                      plan["prediction"][-1], motion["prediction"][-1], ego["status"][-1]])
+    # Two EAGER runs of this sequence already differ: MIOpen picks among bf16 solvers per process and the det
+    # branch re-orders its queries by top-k on near-tied scores of random weights (tools/diag_infer_graph.py:
+    # det rows permute, map / plan / ego agree to ~1e-3).  So: order-free outputs tightly, det through its sorted
+    # score profile.
+    names = ["det_cls", "det_box", "map_pts", "plan_cls", "plan_reg", "motion_reg", "ego_status"]
+    for n, x, y in zip(names, *heads):
+        x, y = x.double(), y.double()
+        if n in ("map_pts", "plan_cls", "plan_reg", "ego_status"):
+            assert float((x - y).abs().max()) <= 1e-2 * max(1.0, float(x.abs().max())), n
+        elif n == "det_cls":
+            sx, sy = x.max(-1).values.sort().values, y.max(-1).values.sort().values
+            assert float((sx - sy).abs().max()) <= 0.15 * max(1.0, float(sx.abs().max())), n
