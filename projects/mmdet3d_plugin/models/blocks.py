@@ -27,7 +27,8 @@ from hipad_amd.compat import (ATTENTION, FEEDFORWARD_NETWORK, PLUGIN_LAYERS, Bas
 
 from ..ops import deformable_aggregation_function as DAF
 
-__all__ = ["DeformableFeatureAggregation", "DenseDepthNet", "AsymmetricFFN", "linear_relu_ln", "CustomOperation"]
+__all__ = ["DeformableFeatureAggregation", "DenseDepthNet", "AsymmetricFFN", "linear_relu_ln", "CustomOperation",
+           "score_head", "mlp_head"]
 
 
 def linear_relu_ln(embed_dims, in_loops, out_loops, input_dims=None):
@@ -40,6 +41,16 @@ def linear_relu_ln(embed_dims, in_loops, out_loops, input_dims=None):
             width_in = embed_dims
         stack.append(LayerNorm(embed_dims))
     return stack
+
+
+def score_head(embed_dims, out_dim=1):
+    """[Linear, ReLU, LayerNorm] x 2 then a Linear to ``out_dim`` logits (Sequential indices 0..6)."""
+    return Sequential(*linear_relu_ln(embed_dims, 1, 2), Linear(embed_dims, out_dim))
+
+
+def mlp_head(embed_dims, out_dim):
+    """[Linear, ReLU] x 2 then a Linear to ``out_dim`` values (Sequential indices 0..4)."""
+    return Sequential(*linear_relu(embed_dims, embed_dims), *linear_relu(embed_dims, embed_dims), Linear(embed_dims, out_dim))
 
 
 @ATTENTION.register_module()
