@@ -61,11 +61,13 @@ class SparseDetector(BaseModule):
             levels = self.img_backbone(img)
             if self.img_neck is not None:
                 levels = self.img_neck(levels)
-        levels = [f.float().reshape((bs, num_cams) + f.shape[1:]) for f in levels]
+        # levels stay in the encoder's dtype (bf16): the depth heads and the flat-layout copy convert on read,
+        # so the pyramid is written once in fp32 (as the flat tensor) instead of twice
+        levels = [f.reshape((bs, num_cams) + f.shape[1:]) for f in levels]
         depths = None
         if return_depth and self.depth_branch is not None:
             depths = self.depth_branch(levels, None if metas is None else metas.get("focal"))
-        feature_maps = feature_maps_format(levels)
+        feature_maps = feature_maps_format(levels, out_dtype=torch.float32)
         feature_maps[0] = shared_feature_grad(feature_maps[0])
         return (feature_maps, depths) if return_depth else feature_maps
 

@@ -54,12 +54,14 @@ def _tables(level_hw, num_cams, device):
 _tables.cache = {}
 
 
-def _format_one_group(level_maps):
+def _format_one_group(level_maps, out_dtype=None):
     bs, num_cams, C = level_maps[0].shape[:3]
     level_hw = [tuple(int(v) for v in m.shape[-2:]) for m in level_maps]
     per_cam = sum(h * w for h, w in level_hw)
     first = level_maps[0]
-    col = torch.empty(bs, num_cams, per_cam, C, dtype=first.dtype, device=first.device)
+    # out_dtype: the encoder hands over bf16 channels-last levels; the copy below then converts to the fp32 the
+    # aggregation kernels read in the same pass (no separate .float() of every level)
+    col = torch.empty(bs, num_cams, per_cam, C, dtype=out_dtype or first.dtype, device=first.device)
     off = 0
     for m, (h, w) in zip(level_maps, level_hw):
         # (bs,cams,C,h,w) -> (bs,cams,h*w,C) written straight into its slot (no cat pass);
@@ -106,9 +108,11 @@ def _inverse(col_feats, spatial_shape, scale_start_index):
     return out
 
 
-def feature_maps_format(feature_maps, inverse=False):
+def feature_maps_format(feature_maps, inverse=False, out_dtype=None):
+    """``out_dtype`` (ours, optional): dtype of the flat tensor when it should differ from the levels' (the
+    reference casts the levels to fp32 first, sparse_detector.py:84-89)."""
     if inverse:
         return _inverse(*feature_maps)
     if isinstance(feature_maps[0], (list, tuple)):
-        return list(_merge_groups([_format_one_group(g) for g in feature_maps]))
-    return list(_format_one_group(feature_maps))
+        return list(_merge_groups([_format_one_group(g, out_dtype) for g in feature_maps]))
+    return list(_format_one_group(feature_maps, out_dtype))
