@@ -131,18 +131,17 @@ __device__ __forceinline__ void lstore_trans(short (*T)[LDS_STRIDE], const float
 //   B_TRANS: B_op[n][k] = B[k * ldb + n]  else B[n * ldb + k]
 //   EPI 0: C = relu?(acc + bias[n])  stored;   EPI 1: atomicAdd(C, acc) + optional row sums of A_op
 //   grid = (ceil(N/32), ceil(M/64), splits over the reduction); k_per_split is a multiple of KC
+// One 64 x 32 output tile (tile coordinates bx, by, split bz) of the product; TA / TB: the workgroup's LDS.
 template <bool A_TRANS, bool B_TRANS, int EPI, bool VA, bool VB>
-__global__ __launch_bounds__(256) void gemm_kernel(float *__restrict__ C, const float *__restrict__ A,
-                                                   const float *__restrict__ A_gate, const float *__restrict__ B,
-                                                   const float *__restrict__ bias, float *__restrict__ rowsum_out,
-                                                   int M, int N, int K, int lda, int ldb, int ldc, int relu,
-                                                   int k_per_split) {
-  __shared__ short TA[BM][LDS_STRIDE];
-  __shared__ short TB[BN][LDS_STRIDE];
+__device__ __forceinline__ void gemm_tile(short (*TA)[LDS_STRIDE], short (*TB)[LDS_STRIDE], float *__restrict__ C,
+                                          const float *__restrict__ A, const float *__restrict__ A_gate,
+                                          const float *__restrict__ B, const float *__restrict__ bias,
+                                          float *__restrict__ rowsum_out, int M, int N, int K, int lda, int ldb, int ldc,
+                                          int relu, int k_per_split, int bx, int by, int bz) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int l15 = lane & 15, quad = lane >> 4;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
+  const int m0 = by * BM, n0 = bx * BN;
+  const int kbeg = bz * k_per_split, kend = min(K, kbeg + k_per_split);
   f32x4 acc[2];
   acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
   acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -177,7 +176,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(float *__restrict__ C, const 
       acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, acc[1], 0, 0, 0);
     }
-    if (EPI == 1 && rowsum_out && blockIdx.x == 0) {
+    if (EPI == 1 && rowsum_out && bx == 0) {
       // sum over the chunk of A_op[row = tid/4][.]: each thread a quarter of the row, then 2 shuffles
       const int row = tid >> 2, q = tid & 3;
       float s8 = 0.f;
@@ -213,8 +212,51 @@ __global__ __launch_bounds__(256) void gemm_kernel(float *__restrict__ C, const 
       }
     }
   }
-  if (EPI == 1 && rowsum_out && blockIdx.x == 0 && (tid & 3) == 0 && m0 + (tid >> 2) < M)
+  if (EPI == 1 && rowsum_out && bx == 0 && (tid & 3) == 0 && m0 + (tid >> 2) < M)
     atomicAdd(rowsum_out + m0 + (tid >> 2), rsum);
+}
+
+template <bool A_TRANS, bool B_TRANS, int EPI, bool VA, bool VB>
+__global__ __launch_bounds__(256) void gemm_kernel(float *__restrict__ C, const float *__restrict__ A,
+                                                   const float *__restrict__ A_gate, const float *__restrict__ B,
+                                                   const float *__restrict__ bias, float *__restrict__ rowsum_out,
+                                                   int M, int N, int K, int lda, int ldb, int ldc, int relu,
+                                                   int k_per_split) {
+  __shared__ short TA[BM][LDS_STRIDE];
+  __shared__ short TB[BN][LDS_STRIDE];
+  gemm_tile<A_TRANS, B_TRANS, EPI, VA, VB>(TA, TB, C, A, A_gate, B, bias, rowsum_out, M, N, K, lda, ldb, ldc, relu,
+                                           k_per_split, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Backward of a Linear in ONE launch: the first `dx_tiles` workgroups compute dX = (dY o gate) W (overwrite), the
+// others dW += (dY o gate)^T X and db += colsum(dY o gate) (atomics).  Two launches per layer were two trips through
+// the ~4 us dispatch floor that dominates these tiny products.
+//   VDY / VW / VX: 16-byte vector loads allowed on dY (and the gate), W, X.
+struct LinBwdArgs {
+  float *dx, *dw, *db;
+  const float *dy, *gate, *x, *w;
+  int M, N, K;
+  int dx_tiles_x, dx_tiles;          // dX grid: dx_tiles_x column tiles, dx_tiles in total
+  int dw_tiles_x, dw_tiles_xy;       // dW grid: column tiles, tiles per split
+  int dx_kper, dw_kper;
+};
+
+template <bool VDY, bool VW, bool VX>
+__global__ __launch_bounds__(256) void linear_bwd_fused_kernel(LinBwdArgs a) {
+  __shared__ short TA[BM][LDS_STRIDE];
+  __shared__ short TB[BN][LDS_STRIDE];
+  const int b = blockIdx.x;
+  if (b < a.dx_tiles) {
+    // dX[m][k] = sum_n dYg[m][n] W[n][k]: A = dY row-major, B_op[k][n] = W[n*K + k] (strided)
+    gemm_tile<false, true, 0, VDY, VW>(TA, TB, a.dx, a.dy, a.gate, a.w, nullptr, nullptr, a.M, a.K, a.N, a.N, a.K, a.K,
+                                       0, a.dx_kper, b % a.dx_tiles_x, b / a.dx_tiles_x, 0);
+  } else {
+    // dW[n][k] += sum_m dYg[m][n] X[m][k]: A_op[n][m] = dY[m*N + n], B_op[k][m] = X[m*K + k] (both strided)
+    const int t = b - a.dx_tiles;
+    const int bz = t / a.dw_tiles_xy, r = t - bz * a.dw_tiles_xy;
+    gemm_tile<true, true, 1, VDY, VX>(TA, TB, a.dw, a.dy, a.gate, a.x, nullptr, a.db, a.N, a.K, a.M, a.N, a.K, a.K, 0,
+                                      a.dw_kper, r % a.dw_tiles_x, r / a.dw_tiles_x, bz);
+  }
 }
 
 static inline int vec_ok(const void *p, int ld) { return (((uintptr_t)p & 15) == 0 && (ld & 3) == 0) ? 1 : 0; }
@@ -264,6 +306,36 @@ int hipad_linear_backward(float *dx, float *dw, float *db, const float *dy, cons
   if (!dy || !x || !weight) return HIPAD_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   const int vdy = vec_ok(dy, N) & (y_relu ? vec_ok(y_relu, N) : 1);
+  if (dx && dw && N <= 4 * KC) {
+    // the common case: both gradients, short reduction for dX -> one fused launch
+    LinBwdArgs a;
+    a.dx = dx; a.dw = dw; a.db = db; a.dy = dy; a.gate = y_relu; a.x = x; a.w = weight;
+    a.M = M; a.N = N; a.K = K;
+    a.dx_tiles_x = (K + BN - 1) / BN;
+    a.dx_tiles = a.dx_tiles_x * ((M + BM - 1) / BM);
+    a.dx_kper = (N + KC - 1) / KC * KC;
+    a.dw_tiles_x = (K + BN - 1) / BN;
+    a.dw_tiles_xy = a.dw_tiles_x * ((N + BM - 1) / BM);
+    int per = KC;
+    while ((long long)a.dw_tiles_xy * ((M + per - 1) / per) > 4096 && per < M) per += KC;
+    a.dw_kper = per;
+    const int splits = (M + per - 1) / per;
+    const long long blocks = (long long)a.dx_tiles + (long long)a.dw_tiles_xy * splits;
+    if (blocks < (1ll << 31)) {
+      const dim3 grid((unsigned)blocks);
+      const int vw = vec_ok(weight, K), vx = vec_ok(x, K);
+#define HIPAD_LBF(A_, B_, C_) hipLaunchKernelGGL((linear_bwd_fused_kernel<A_, B_, C_>), grid, dim3(256), 0, stream, a)
+      if (vdy) {
+        if (vw) { if (vx) HIPAD_LBF(true, true, true); else HIPAD_LBF(true, true, false); }
+        else { if (vx) HIPAD_LBF(true, false, true); else HIPAD_LBF(true, false, false); }
+      } else {
+        if (vw) { if (vx) HIPAD_LBF(false, true, true); else HIPAD_LBF(false, true, false); }
+        else { if (vx) HIPAD_LBF(false, false, true); else HIPAD_LBF(false, false, false); }
+      }
+#undef HIPAD_LBF
+      return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
+    }
+  }
   if (dx) {
     // dX[m][k] = sum_n dYm[m][n] W[n][k]  : A = dY (row-major over n), B_op[k][n] = W[n*K + k] (transposed)
     const int tiles = ((K + BN - 1) / BN) * ((M + BM - 1) / BM);
