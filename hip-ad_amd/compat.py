@@ -159,6 +159,27 @@ class Linear(nn.Linear):
         return nn.functional.relu(y) if self.fuse_relu else y
 
 
+class MLPStack(nn.Sequential):
+    """nn.Sequential (same children, same state_dict keys) that runs every [Linear(+ReLU), FusedReLU, LayerNorm]
+    triple as ONE forward launch (hipad_linear_relu_ln_forward) when the shapes allow it."""
+
+    def forward(self, x):
+        from . import functional as HF
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if (i + 2 < len(mods) and isinstance(m, Linear) and m.fuse_relu and isinstance(mods[i + 1], FusedReLU)
+                    and isinstance(mods[i + 2], LayerNorm) and HF.linear_relu_ln_ok(x, m.weight, mods[i + 2].weight)):
+                ln = mods[i + 2]
+                x = HF.linear_relu_ln(x, m.weight, m.bias, ln.weight, ln.bias, ln.eps)
+                i += 3
+            else:
+                x = m(x)
+                i += 1
+        return x
+
+
 def linear_relu(in_features, out_features):
     """(Linear with the ReLU fused into its epilogue, placeholder) -- two modules, so Sequential
     indices (and therefore state_dict keys) match a plain [Linear, ReLU] pair."""

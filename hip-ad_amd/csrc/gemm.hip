@@ -259,6 +259,177 @@ __global__ __launch_bounds__(256) void linear_bwd_fused_kernel(LinBwdArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Linear + ReLU + LayerNorm forward in one launch (the [Linear, ReLU, LayerNorm] unit of every linear_relu_ln stack,
+// reference models/blocks.py:32-42): a workgroup owns 32 full rows (N <= 256 outputs), so the LayerNorm statistics
+// are available in its epilogue.  Writes xr = relu(x W^T + b) (kept for the backward) and y = LN(xr).
+//   CT = 16-column MFMA tiles per wave (N = 64 * CT for CT in {1,2,4}; N = 32/16: CT = 1 with idle waves).
+// Reduction in chunks of 128; weights are re-read from L2 by every workgroup (<= 256 KiB).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int LR = 32;            // rows per workgroup
+constexpr int KC2 = 128;          // reduction chunk
+constexpr int LDS2 = KC2 + 8;
+
+template <int ROWS>
+__device__ __forceinline__ void gload_rm128(float4 (&v)[ROWS / 8], const float *__restrict__ src, int ld, int r0, int k0,
+                                            int rows, int kend, int tid) {
+  const int kk = (tid & 15) * 8, rr = tid >> 4;  // 16 threads per row, 16 rows per pass
+  const int gk = k0 + kk;
+  const int n0 = max(0, min(4, kend - gk)), n1 = max(0, min(4, kend - gk - 4));
+#pragma unroll
+  for (int p = 0; p < ROWS / 16; ++p) {
+    const int gr = r0 + rr + 16 * p;
+    const bool in = gr < rows;
+    const float *q = src + (size_t)(in ? gr : 0) * ld + gk;
+    v[2 * p] = ld4<true>(q, src, in ? n0 : 0);
+    v[2 * p + 1] = ld4<true>(q + 4, src, in ? n1 : 0);
+  }
+}
+template <int ROWS>
+__device__ __forceinline__ void lstore_rm128(short (*T)[LDS2], const float4 (&v)[ROWS / 8], int tid) {
+  const int kk = (tid & 15) * 8, rr = tid >> 4;
+#pragma unroll
+  for (int p = 0; p < ROWS / 16; ++p) {
+    const float4 a = v[2 * p], b = v[2 * p + 1];
+    *reinterpret_cast<bf16x8 *>(&T[rr + 16 * p][kk]) = pack8(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
+  }
+}
+
+template <int CT>
+__global__ __launch_bounds__(256) void linear_relu_ln_fwd_kernel(
+    float *__restrict__ y, float *__restrict__ xr, float *__restrict__ mean_out, float *__restrict__ rstd_out,
+    const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+    const float *__restrict__ gamma, const float *__restrict__ beta, int M, int N, int K, float eps) {
+  constexpr int NB = 64 * CT;  // weight rows staged in LDS (>= N)
+  __shared__ short TA[LR][LDS2];
+  __shared__ short TB[NB][LDS2];
+  __shared__ float red[4][LR];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l15 = lane & 15, quad = lane >> 4;
+  const int m0 = blockIdx.x * LR;
+  f32x4 acc[2][CT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < CT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 ra[LR / 8], rb[NB / 8];
+  gload_rm128<LR>(ra, x, K, m0, 0, M, K, tid);
+  gload_rm128<NB>(rb, w, K, 0, 0, N, K, tid);
+  for (int k0 = 0; k0 < K; k0 += KC2) {
+    lstore_rm128<LR>(TA, ra, tid);
+    lstore_rm128<NB>(TB, rb, tid);
+    __syncthreads();
+    if (k0 + KC2 < K) {
+      gload_rm128<LR>(ra, x, K, m0, k0 + KC2, M, K, tid);
+      gload_rm128<NB>(rb, w, K, 0, k0 + KC2, N, K, tid);
+    }
+    const int nsteps = (min(KC2, K - k0) + 31) >> 5;
+    for (int s = 0; s < nsteps; ++s) {
+      const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(&TA[l15][32 * s + 8 * quad]);
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(&TA[16 + l15][32 * s + 8 * quad]);
+#pragma unroll
+      for (int j = 0; j < CT; ++j) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&TB[16 * (wv * CT + j) + l15][32 * s + 8 * quad]);
+        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[1][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // element (i, j, r): row = 16 i + 4 quad + r, col = 16 (wv CT + j) + l15
+  float v[2][CT][4];
+  float psum[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) psum[i][r] = 0.f;
+#pragma unroll
+  for (int j = 0; j < CT; ++j) {
+    const int col = 16 * (wv * CT + j) + l15;
+    const bool cok = col < N;
+    const float bv = (bias && cok) ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float t = cok ? fmaxf(acc[i][j][r] + bv, 0.f) : 0.f;
+        v[i][j][r] = t;
+        psum[i][r] += t;
+      }
+  }
+  auto row_total = [&](float (&ps)[2][4], float (&tot)[2][4]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = ps[i][r];
+        t += __shfl_xor(t, 8); t += __shfl_xor(t, 4); t += __shfl_xor(t, 2); t += __shfl_xor(t, 1);
+        if (l15 == 0) red[wv][16 * i + 4 * quad + r] = t;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * i + 4 * quad + r;
+        tot[i][r] = red[0][row] + red[1][row] + red[2][row] + red[3][row];
+      }
+    __syncthreads();
+  };
+  float mean[2][4], var[2][4];
+  row_total(psum, mean);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      mean[i][r] /= (float)N;
+      psum[i][r] = 0.f;
+    }
+#pragma unroll
+  for (int j = 0; j < CT; ++j) {
+    const bool cok = 16 * (wv * CT + j) + l15 < N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = cok ? v[i][j][r] - mean[i][r] : 0.f;
+        psum[i][r] += d * d;
+      }
+  }
+  row_total(psum, var);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) var[i][r] = rsqrtf(var[i][r] / (float)N + eps);  // var now holds rstd
+#pragma unroll
+  for (int j = 0; j < CT; ++j) {
+    const int col = 16 * (wv * CT + j) + l15;
+    if (col >= N) continue;
+    const float gm = gamma ? gamma[col] : 1.f, bt = beta ? beta[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + 16 * i + 4 * quad + r;
+        if (row >= M) continue;
+        xr[(size_t)row * N + col] = v[i][j][r];
+        y[(size_t)row * N + col] = (v[i][j][r] - mean[i][r]) * var[i][r] * gm + bt;
+      }
+  }
+  if (wv == 0 && l15 == 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + 16 * i + 4 * quad + r;
+        if (row < M) {
+          mean_out[row] = mean[i][r];
+          rstd_out[row] = var[i][r];
+        }
+      }
+  }
+}
+
 static inline int vec_ok(const void *p, int ld) { return (((uintptr_t)p & 15) == 0 && (ld & 3) == 0) ? 1 : 0; }
 
 // launch gemm_kernel<AT, BT, EPI, va, vb> with the two vector-load flags resolved at run time
@@ -296,6 +467,23 @@ int hipad_linear_forward(float *y, const float *x, const float *weight, const fl
   // C[m][n] = sum_k X[m][k] W[n][k]
   HIPAD_GEMM(false, false, 0, vec_ok(x, K), vec_ok(weight, K), grid, (hipStream_t)stream, y, x,
              (const float *)nullptr, weight, bias, (float *)nullptr, M, N, K, K, K, N, relu, kall);
+  return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
+}
+
+int hipad_linear_relu_ln_supported(int N, int K) { return (N >= 16 && N <= 256 && N % 16 == 0 && K % 4 == 0) ? 1 : 0; }
+
+int hipad_linear_relu_ln_forward(float *y, float *x_relu, float *mean, float *rstd, const float *x, const float *weight,
+                                 const float *bias, const float *gamma, const float *beta, int M, int N, int K,
+                                 float eps, hipad_stream_t stream) {
+  int rc = check_lin(M, N, K);
+  if (rc != HIPAD_OK) return rc;
+  if (!y || !x_relu || !mean || !rstd || !x || !weight) return HIPAD_EINVAL;
+  if (!hipad_linear_relu_ln_supported(N, K) || !vec_ok(x, K) || !vec_ok(weight, K)) return HIPAD_EINVAL;
+  const dim3 grid((M + LR - 1) / LR);
+#define HIPAD_LRL(CT_) hipLaunchKernelGGL((linear_relu_ln_fwd_kernel<CT_>), grid, dim3(256), 0, (hipStream_t)stream, y, \
+                                           x_relu, mean, rstd, x, weight, bias, gamma, beta, M, N, K, eps)
+  if (N <= 64) HIPAD_LRL(1); else if (N <= 128) HIPAD_LRL(2); else HIPAD_LRL(4);
+#undef HIPAD_LRL
   return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
 }
 

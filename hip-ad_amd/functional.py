@@ -271,3 +271,54 @@ def layer_norm(x, weight, bias, eps=1e-5):
     if not x.is_cuda or n % 4 or n > 1024 or x.dtype != torch.float32:
         return torch.nn.functional.layer_norm(x, (n,), weight, bias, eps)
     return _LayerNorm.apply(x, weight, bias, float(eps))
+
+
+class _LinearReluLN(Function):
+    """LayerNorm(relu(x W^T + b)) in one forward launch; backward = the LayerNorm kernel + the fused Linear backward,
+    parameter gradients accumulated in place like _Linear / _LayerNorm."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, eps):
+        shape = x.shape
+        x2 = _c32(x.reshape(-1, shape[-1]))
+        y, xr, mean, rstd = _lib.linear_relu_ln_forward(x2, weight.detach(), None if bias is None else bias.detach(),
+                                                        gamma.detach(), beta.detach(), eps)
+        ctx.save_for_backward(x2, xr, mean, rstd)
+        ctx.params, ctx.in_shape = (weight, bias, gamma, beta), shape
+        return y.view(*shape[:-1], weight.shape[0])
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2, xr, mean, rstd = ctx.saved_tensors
+        weight, bias, gamma, beta = ctx.params
+        dy2 = _c32(dy.reshape(xr.shape))
+        rets = [None] * 4
+
+        def target(i, p):
+            g = p.grad if LINEAR_INPLACE_GRAD else None
+            if g is not None and g.is_contiguous() and g.dtype == torch.float32:
+                INPLACE_PARAMS.add(id(p))
+                return g
+            rets[i] = torch.zeros_like(p)
+            return rets[i]
+
+        dxr = torch.empty_like(xr)
+        _lib.layernorm_backward(dy2, xr, mean, rstd, gamma.detach(), dxr, target(2, gamma), target(3, beta))
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        _lib.linear_backward(dxr, xr, x2, weight.detach(), dx, target(0, weight), None if bias is None else target(1, bias))
+        return (dx.view(ctx.in_shape) if dx is not None else None), rets[0], rets[1], rets[2], rets[3], None
+
+
+def linear_relu_ln(x, weight, bias, gamma, beta, eps=1e-5):
+    """[Linear, ReLU, LayerNorm] unit on one forward kernel; callers check ``linear_relu_ln_ok`` first."""
+    return _LinearReluLN.apply(x, weight, bias, gamma, beta, float(eps))
+
+
+def linear_relu_ln_ok(x, weight, gamma):
+    if not (x.is_cuda and LINEAR_MODE == "mfma_bf16" and x.dtype == torch.float32 and gamma is not None):
+        return False
+    if not (weight.requires_grad or not torch.is_grad_enabled() or True):
+        return False
+    n, k = weight.shape
+    return 16 <= n <= 256 and n % 16 == 0 and k % 4 == 0 and weight.data_ptr() % 16 == 0

@@ -30,6 +30,8 @@ SIGNATURES = {
     "hipad_weights_softmax_backward": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p, c_size_t, c_void_p]),
     "hipad_linear_forward": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "hipad_linear_backward": (c_int, [c_void_p] * 7 + [c_int] * 3 + [c_void_p]),
+    "hipad_linear_relu_ln_supported": (c_int, [c_int, c_int]),
+    "hipad_linear_relu_ln_forward": (c_int, [c_void_p] * 9 + [c_int] * 3 + [ctypes.c_float, c_void_p]),
     "hipad_layernorm_forward": (c_int, [c_void_p] * 6 + [c_int, c_int, ctypes.c_float, c_void_p]),
     "hipad_layernorm_backward": (c_int, [c_void_p] * 8 + [c_int, c_int, c_void_p]),
     "hipad_linear_assignment": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
@@ -370,3 +372,27 @@ def linear_assignment(cost, n_rows):
         st = lib.hipad_linear_assignment(out.data_ptr(), cost.data_ptr(), n_rows.data_ptr(), B, R, C, stream_ptr(cost.device))
     check(st, "hipad_linear_assignment")
     return out
+
+
+def linear_relu_ln_supported(x2, weight):
+    lib = load()
+    return bool(lib.hipad_linear_relu_ln_supported(weight.shape[0], weight.shape[1])) and x2.data_ptr() % 16 == 0 \
+        and weight.data_ptr() % 16 == 0
+
+
+def linear_relu_ln_forward(x2, weight, bias, gamma, beta, eps):
+    """x2 (M,K) -> y = LayerNorm(relu(x2 W^T + b)) (M,N), x_relu (M,N), mean (M,), rstd (M,)."""
+    lib = load()
+    _req(x2, torch.float32, "x")
+    M, K = x2.shape
+    N = weight.shape[0]
+    y = torch.empty(M, N, dtype=torch.float32, device=x2.device)
+    xr = torch.empty_like(y)
+    mean = torch.empty(M, dtype=torch.float32, device=x2.device)
+    rstd = torch.empty_like(mean)
+    with torch.cuda.device(x2.device):
+        st = lib.hipad_linear_relu_ln_forward(y.data_ptr(), xr.data_ptr(), mean.data_ptr(), rstd.data_ptr(), x2.data_ptr(),
+                                              weight.data_ptr(), _ptr(bias), _ptr(gamma), _ptr(beta), M, N, K, float(eps),
+                                              stream_ptr(x2.device))
+    check(st, "hipad_linear_relu_ln_forward")
+    return y, xr, mean, rstd

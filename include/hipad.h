@@ -202,6 +202,14 @@ int hipad_attention_backward(float *dq, float *dk, float *dv, float *delta_ws, c
  * ---------------------------------------------------------------------------------- */
 int hipad_linear_forward(float *y, const float *x, const float *weight, const float *bias, int M, int N,
                          int K, int relu, hipad_stream_t stream);
+/* Linear + ReLU + LayerNorm forward in one launch (the [Linear, ReLU, LayerNorm] unit of the reference's
+ * linear_relu_ln stacks, models/blocks.py:32-42): x_relu[M,N] = relu(x weight^T + bias) and y = LayerNorm(x_relu)
+ * with mean / rstd [M] for the backward, which is hipad_layernorm_backward followed by hipad_linear_backward
+ * (y_relu = x_relu).  Supported when hipad_linear_relu_ln_supported(N, K) and x / weight are 16-byte aligned. */
+int hipad_linear_relu_ln_supported(int N, int K);
+int hipad_linear_relu_ln_forward(float *y, float *x_relu, float *mean, float *rstd, const float *x,
+                                 const float *weight, const float *bias, const float *gamma, const float *beta,
+                                 int M, int N, int K, float eps, hipad_stream_t stream);
 int hipad_linear_backward(float *dx, float *dw, float *db, const float *dy, const float *y_relu,
                           const float *x, const float *weight, int M, int N, int K, hipad_stream_t stream);
 

@@ -7,7 +7,7 @@ Registered names / constructor keywords / parameter names follow the reference's
 import torch
 import torch.nn as nn
 
-from hipad_amd.compat import (PLUGIN_LAYERS, POSITIONAL_ENCODING, BaseModule, Linear, Scale, bias_init_with_prob,
+from hipad_amd.compat import (MLPStack, PLUGIN_LAYERS, POSITIONAL_ENCODING, BaseModule, Linear, Scale, bias_init_with_prob,
                               xavier_init)
 from projects.mmdet3d_plugin.core.box3d import COS_YAW, H, L, SIN_YAW, VX, W, X, Y, Z
 
@@ -29,7 +29,7 @@ class SparseBox3DEncoder(BaseModule):
         widths = list(embed_dims) if isinstance(embed_dims, (list, tuple)) else [embed_dims] * 5
 
         def mlp(n_in, n_out):
-            return nn.Sequential(*linear_relu_ln(n_out, in_loops, out_loops, n_in))
+            return MLPStack(*linear_relu_ln(n_out, in_loops, out_loops, n_in))
 
         self.pos_fc = mlp(3, widths[0])
         self.size_fc = mlp(3, widths[1])
@@ -58,14 +58,14 @@ class SparseBox3DRefinementModule(BaseModule):
         self.embed_dims, self.output_dim, self.num_cls = embed_dims, output_dim, num_cls
         self.normalize_yaw, self.refine_yaw = normalize_yaw, refine_yaw
         self.refine_state = [X, Y, Z, W, L, H] + ([SIN_YAW, COS_YAW] if refine_yaw else [])
-        self.layers = nn.Sequential(*linear_relu_ln(embed_dims, 2, 2), Linear(embed_dims, output_dim),
+        self.layers = MLPStack(*linear_relu_ln(embed_dims, 2, 2), Linear(embed_dims, output_dim),
                                     Scale([1.0] * output_dim))
         self.with_cls_branch = with_cls_branch
         if with_cls_branch:
-            self.cls_layers = nn.Sequential(*linear_relu_ln(embed_dims, 1, 2), Linear(embed_dims, num_cls))
+            self.cls_layers = MLPStack(*linear_relu_ln(embed_dims, 1, 2), Linear(embed_dims, num_cls))
         self.with_quality_estimation = with_quality_estimation
         if with_quality_estimation:
-            self.quality_layers = nn.Sequential(*linear_relu_ln(embed_dims, 1, 2), Linear(embed_dims, 2))
+            self.quality_layers = MLPStack(*linear_relu_ln(embed_dims, 1, 2), Linear(embed_dims, 2))
 
     def init_weight(self):
         if self.with_cls_branch:

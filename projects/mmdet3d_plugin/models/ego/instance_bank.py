@@ -10,7 +10,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from hipad_amd.compat import PLUGIN_LAYERS, Linear, build_from_cfg
+from hipad_amd.compat import MLPStack, PLUGIN_LAYERS, Linear, build_from_cfg
 from projects.mmdet3d_plugin.ops import feature_maps_format
 
 from ..blocks import linear_relu_ln
@@ -49,7 +49,7 @@ class EgoInstanceBank(PersistentState, nn.Module):
             self.ego_feature_encoder = front_view_encoder(embed_dims, feature_map_scale)
         if plan_anchor is not None:
             self.plan_anchor = nn.Parameter(torch.tensor(np.load(plan_anchor), dtype=torch.float32), requires_grad=False)
-            self.plan_anchor_encoder = nn.Sequential(*linear_relu_ln(embed_dims, 1, 1), Linear(embed_dims, embed_dims))
+            self.plan_anchor_encoder = MLPStack(*linear_relu_ln(embed_dims, 1, 1), Linear(embed_dims, embed_dims))
         self.reset()
 
     def reset(self):

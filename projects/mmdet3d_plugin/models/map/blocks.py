@@ -10,7 +10,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from hipad_amd.compat import (PLUGIN_LAYERS, POSITIONAL_ENCODING, BaseModule, Linear, Scale, bias_init_with_prob,
+from hipad_amd.compat import (MLPStack, PLUGIN_LAYERS, POSITIONAL_ENCODING, BaseModule, Linear, Scale, bias_init_with_prob,
                               xavier_init)
 
 from ..blocks import linear_relu_ln
@@ -29,7 +29,7 @@ class SparsePoint3DEncoder(BaseModule):
         self.embed_dims = embed_dims
         self.input_dims = num_sample * coords_dim
         self.return_points_embed = return_points_embed
-        self.pos_fc = nn.Sequential(*linear_relu_ln(embed_dims, 1, 2, self.input_dims))
+        self.pos_fc = MLPStack(*linear_relu_ln(embed_dims, 1, 2, self.input_dims))
 
     def forward(self, anchor: torch.Tensor):
         embed = self.pos_fc(anchor)
@@ -44,8 +44,8 @@ class KeyPoint3DEncoder(BaseModule):
         super().__init__()
         self.embed_dims, self.coords_dim, self.num_sample = embed_dims, coords_dim, num_sample
         self.input_dims = num_sample * coords_dim
-        self.embed_points = nn.Sequential(*linear_relu_ln(embed_dims, 1, 2, coords_dim))
-        self.embed_instance = nn.Sequential(*linear_relu_ln(embed_dims, 1, 2, self.input_dims))
+        self.embed_points = MLPStack(*linear_relu_ln(embed_dims, 1, 2, coords_dim))
+        self.embed_instance = MLPStack(*linear_relu_ln(embed_dims, 1, 2, self.input_dims))
 
     def forward(self, anchor: torch.Tensor):
         bs, num_anchor, _ = anchor.shape
@@ -63,11 +63,11 @@ class SparsePoint3DRefinementModule(BaseModule):
         self.embed_dims, self.num_sample, self.num_cls = embed_dims, num_sample, num_cls
         self.with_line_key_points = with_line_key_points
         self.output_dim = coords_dim if with_line_key_points else num_sample * coords_dim
-        self.layers = nn.Sequential(*linear_relu_ln(embed_dims, 2, 2), Linear(embed_dims, self.output_dim),
+        self.layers = MLPStack(*linear_relu_ln(embed_dims, 2, 2), Linear(embed_dims, self.output_dim),
                                     Scale([1.0] * self.output_dim))
         self.with_cls_branch = with_cls_branch
         if with_cls_branch:
-            self.cls_layers = nn.Sequential(*linear_relu_ln(embed_dims, 1, 2), Linear(embed_dims, num_cls))
+            self.cls_layers = MLPStack(*linear_relu_ln(embed_dims, 1, 2), Linear(embed_dims, num_cls))
 
     def init_weight(self):
         if self.with_cls_branch:

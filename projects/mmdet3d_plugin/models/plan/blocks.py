@@ -3,7 +3,7 @@ models/plan/blocks.py:16-157)."""
 import torch
 import torch.nn as nn
 
-from hipad_amd.compat import PLUGIN_LAYERS, BaseModule, Linear, Scale, bias_init_with_prob
+from hipad_amd.compat import MLPStack, PLUGIN_LAYERS, BaseModule, Linear, Scale, bias_init_with_prob
 
 from ..blocks import linear_relu_ln
 
@@ -11,11 +11,11 @@ __all__ = ["SparsePlanRefinementModule", "SparsePlanAlignRefinementModule"]
 
 
 def _cls_head(embed_dims):
-    return nn.Sequential(*linear_relu_ln(embed_dims, 1, 2), Linear(embed_dims, 1))
+    return MLPStack(*linear_relu_ln(embed_dims, 1, 2), Linear(embed_dims, 1))
 
 
 def _reg_head(embed_dims, out_dim):
-    return nn.Sequential(*linear_relu_ln(embed_dims, 2, 2), Linear(embed_dims, out_dim), Scale([1.0] * out_dim))
+    return MLPStack(*linear_relu_ln(embed_dims, 2, 2), Linear(embed_dims, out_dim), Scale([1.0] * out_dim))
 
 
 @PLUGIN_LAYERS.register_module()

@@ -22,7 +22,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from hipad_amd.compat import (ATTENTION, BBOX_CODERS, BBOX_SAMPLERS, FEEDFORWARD_NETWORK, HEADS, LOSSES, NORM_LAYERS,
+from hipad_amd.compat import (MLPStack, ATTENTION, BBOX_CODERS, BBOX_SAMPLERS, FEEDFORWARD_NETWORK, HEADS, LOSSES, NORM_LAYERS,
                               PLUGIN_LAYERS, POSITIONAL_ENCODING, BaseModule, Linear, build_from_cfg)
 from projects.mmdet3d_plugin.core.box3d import COS_YAW, SIN_YAW
 
@@ -225,13 +225,13 @@ class SparseOneDecoder(DecoderLoss, BaseModule):
             self.plan_anchor_types = self.plan_instance_bank.anchor_types
             self.plan_speed_refer, self.plan_anchor_refer = plan_speed_refer, plan_anchor_refer
             if with_command_embed:
-                self.command_embed_encoder = nn.Sequential(*linear_relu_ln(embed_dims, 2, 1, input_dims=num_command),
+                self.command_embed_encoder = MLPStack(*linear_relu_ln(embed_dims, 2, 1, input_dims=num_command),
                                                            Linear(embed_dims, embed_dims))
             if with_target_point_embed:
-                self.target_point_encoder = nn.Sequential(*linear_relu_ln(embed_dims, 2, 1), Linear(embed_dims, embed_dims))
+                self.target_point_encoder = MLPStack(*linear_relu_ln(embed_dims, 2, 1), Linear(embed_dims, embed_dims))
         if "motion" in self.task_select:
             self.motion_anchor = nn.Parameter(torch.tensor(np.load(motion_anchor), dtype=torch.float32), requires_grad=False)
-            self.motion_anchor_encoder = nn.Sequential(*linear_relu_ln(embed_dims, 1, 1), Linear(embed_dims, embed_dims))
+            self.motion_anchor_encoder = MLPStack(*linear_relu_ln(embed_dims, 1, 1), Linear(embed_dims, embed_dims))
             self.motion_refine = stack(motion_refine_layer, PLUGIN_LAYERS, n_refine)
             self.motion_sampler, self.motion_decoder = _optional(motion_sampler, BBOX_SAMPLERS), _optional(motion_decoder, BBOX_CODERS)
             self.loss_motion_cls, self.loss_motion_reg = _optional(loss_motion_cls, LOSSES), _optional(loss_motion_reg, LOSSES)

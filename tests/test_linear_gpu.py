@@ -83,3 +83,54 @@ def test_packed_rows_gradient_lands_in_full_parameter():
     assert rel(y, torch.nn.functional.linear(x, Wr[E:2 * E], br[E:2 * E])) < 1e-2
     assert rel(W.grad, Wr.grad) < 1e-2 and rel(b.grad, br.grad) < 1e-2
     assert float(W.grad[:E].abs().max()) == 0 and float(W.grad[2 * E:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(900, 256, 256), (48, 256, 256), (1, 256, 256), (5400, 256, 256), (900, 128, 128),
+                                   (900, 64, 64), (100, 32, 32), (37, 256, 12), (481, 256, 512), (33, 48, 40)])
+def test_linear_relu_ln_unit_matches_unfused(M, N, K):
+    """The one-launch [Linear, ReLU, LayerNorm] forward (MLPStack) against the same three modules run separately by
+    torch in fp32, with all four parameter gradients accumulated on top of existing .grad buffers."""
+    from hipad_amd import functional as HF
+    g = torch.Generator().manual_seed(M + 7 * N + K)
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda() * 0.3
+    ga = (torch.rand(N, generator=g) + 0.5).cuda()
+    be = torch.randn(N, generator=g).cuda()
+    go = torch.randn(M, N, generator=g).cuda()
+    ps = [torch.nn.Parameter(t.clone()) for t in (w, b, ga, be)]
+    for p in ps:
+        p.grad = torch.full_like(p, 0.25)
+    x1 = x.clone().requires_grad_(True)
+    assert HF.linear_relu_ln_ok(x1, ps[0], ps[2])
+    y = HF.linear_relu_ln(x1, *ps, 1e-5)
+    y.backward(go)
+    x2 = x.clone().requires_grad_(True)
+    rs = [t.clone().requires_grad_(True) for t in (w, b, ga, be)]
+    pre = torch.nn.functional.linear(x2, rs[0], rs[1])
+    # the ReLU gate is evaluated on bf16-operand pre-activations in the kernel: a fraction of a percent of the units
+    # sit on the other side of zero in fp32 (see test_linear_forward_backward); compare under the kernel's own gate
+    from hipad_amd import lib
+    gate = lib.linear_forward(x, w, b, True) > 0
+    assert float((gate != (pre.detach() > 0)).float().mean()) < 1e-2
+    act = pre * gate
+    yr = torch.nn.functional.layer_norm(act, (N,), rs[2], rs[3], 1e-5)
+    yr.backward(go)
+    assert rel_fro(y, yr) < 2e-2
+    assert rel_fro(x1.grad, x2.grad) < 3e-2
+    assert rel_fro(ps[0].grad - 0.25, rs[0].grad) < 3e-2
+    assert rel_fro(ps[1].grad - 0.25, rs[1].grad) < 3e-2
+    assert rel_fro(ps[2].grad - 0.25, rs[2].grad) < 3e-2
+    assert rel_fro(ps[3].grad - 0.25, rs[3].grad) < 3e-2
+
+
+def test_mlp_stack_state_dict_and_output_equal_sequential():
+    from hipad_amd.compat import Linear, MLPStack
+    from projects.mmdet3d_plugin.models.blocks import linear_relu_ln
+    torch.manual_seed(0)
+    fused = MLPStack(*linear_relu_ln(256, 2, 2), Linear(256, 11)).cuda()
+    plain = torch.nn.Sequential(*linear_relu_ln(256, 2, 2), Linear(256, 11)).cuda()
+    plain.load_state_dict(fused.state_dict())
+    assert list(fused.state_dict()) == list(plain.state_dict())
+    x = torch.randn(2, 900, 256).cuda()
+    assert rel_fro(fused(x), plain(x)) < 1e-3   # same kernels' arithmetic up to the order of the reduction chunks
