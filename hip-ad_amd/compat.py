@@ -160,8 +160,8 @@ class Linear(nn.Linear):
 
 
 class MLPStack(nn.Sequential):
-    """nn.Sequential (same children, same state_dict keys) that runs every [Linear(+ReLU), FusedReLU, LayerNorm]
-    triple as ONE forward launch (hipad_linear_relu_ln_forward) when the shapes allow it."""
+    """nn.Sequential (same children, same state_dict keys) that can run every [Linear(+ReLU), FusedReLU, LayerNorm]
+    triple as ONE forward launch (hipad_linear_relu_ln_forward) -- opt-in, see functional.FUSE_LINEAR_LN."""
 
     def forward(self, x):
         from . import functional as HF
@@ -170,7 +170,8 @@ class MLPStack(nn.Sequential):
         while i < len(mods):
             m = mods[i]
             if (i + 2 < len(mods) and isinstance(m, Linear) and m.fuse_relu and isinstance(mods[i + 1], FusedReLU)
-                    and isinstance(mods[i + 2], LayerNorm) and HF.linear_relu_ln_ok(x, m.weight, mods[i + 2].weight)):
+                    and isinstance(mods[i + 2], LayerNorm) and HF.FUSE_LINEAR_LN
+                    and HF.linear_relu_ln_ok(x, m.weight, mods[i + 2].weight)):
                 ln = mods[i + 2]
                 x = HF.linear_relu_ln(x, m.weight, m.bias, ln.weight, ln.bias, ln.eps)
                 i += 3

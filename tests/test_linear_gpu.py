@@ -124,8 +124,10 @@ def test_linear_relu_ln_unit_matches_unfused(M, N, K):
     assert rel_fro(ps[3].grad - 0.25, rs[3].grad) < 3e-2
 
 
-def test_mlp_stack_state_dict_and_output_equal_sequential():
+def test_mlp_stack_state_dict_and_output_equal_sequential(monkeypatch):
+    from hipad_amd import functional as HF
     from hipad_amd.compat import Linear, MLPStack
+    monkeypatch.setattr(HF, "FUSE_LINEAR_LN", True)
     from projects.mmdet3d_plugin.models.blocks import linear_relu_ln
     torch.manual_seed(0)
     fused = MLPStack(*linear_relu_ln(256, 2, 2), Linear(256, 11)).cuda()
