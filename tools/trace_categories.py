@@ -5,11 +5,11 @@ f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 window = float(sys.argv[2]) * 1e6
 steps = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
 CATS = [("encoder (MIOpen conv/BN, bf16 elementwise)", r"igemm|ck::|_ZN2ck|MIOpen|SubTensorOp|BFloat16|bfloat16|max_pool|batch_norm|upsample|Bf16|threshold"),
-        ("linear (hipad gemm)", r"hipad::gemm"),
+        ("linear (hipad gemm, fused backward)", r"hipad::gemm|hipad::linear_"),
         ("aggregation (daf, weights softmax, projection)", r"hipad::daf|hipad::weights_softmax|hipad::project|hipad::fill_zero|hipad::proj"),
         ("attention (hipad)", r"hipad::attn"),
         ("optimizer", r"hipad::adamw|hipad::grad_sqnorm|multi_tensor"),
-        ("layer norm", r"layer_norm|GammaBeta|LayerNorm"),
+        ("layer norm", r"layer_norm|GammaBeta|LayerNorm|hipad::layernorm"),
         ("copies / fills / cat", r"copyBuffer|fillBuffer|FillFunctor|direct_copy|CatArray|copy_kernel"),
         ("reductions", r"reduce_kernel"),
         ("elementwise", r"elementwise|masked_scale|dropout"),
