@@ -328,3 +328,25 @@ def linear_relu_ln_ok(x, weight, gamma):
         return False
     n, k = weight.shape
     return 16 <= n <= 256 and n % 16 == 0 and k % 4 == 0 and weight.data_ptr() % 16 == 0
+
+
+class _BoxPointsProject(Function):
+    @staticmethod
+    def forward(ctx, anchor, fix_scale, learn, projection_mat, image_wh):
+        an, fx, ln = _c32(anchor), _c32(fix_scale), _c32(learn)
+        pm, wh = _c32(projection_mat), _c32(image_wh)
+        ctx.save_for_backward(an, fx, ln, pm, wh)
+        return _lib.box_points_project_forward(an, fx, ln, pm, wh)[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_loc):
+        an, fx, ln, pm, wh = ctx.saved_tensors
+        g_anchor, g_learn = _lib.box_points_project_backward(_c32(grad_loc), an, fx, ln, pm, wh)
+        return g_anchor, None, g_learn, None, None
+
+
+def box_points_project(anchor, fix_scale, learn, projection_mat, image_wh=None):
+    """Box key points (fixed + learnable offsets, yaw rotation, translation) projected into every camera:
+    (bs,A,D) anchors, (n_fix,3) scales, (bs,A,n_learn*3) pre-sigmoid logits or None -> loc (bs,A,P,cams,2)."""
+    return _BoxPointsProject.apply(anchor, fix_scale, learn, projection_mat, image_wh)

@@ -30,6 +30,8 @@ SIGNATURES = {
     "hipad_weights_softmax_backward": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p, c_size_t, c_void_p]),
     "hipad_linear_forward": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "hipad_linear_backward": (c_int, [c_void_p] * 7 + [c_int] * 3 + [c_void_p]),
+    "hipad_box_points_project_forward": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_void_p]),
+    "hipad_box_points_project_backward": (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_void_p]),
     "hipad_linear_relu_ln_supported": (c_int, [c_int, c_int]),
     "hipad_linear_relu_ln_forward": (c_int, [c_void_p] * 9 + [c_int] * 3 + [ctypes.c_float, c_void_p]),
     "hipad_layernorm_forward": (c_int, [c_void_p] * 6 + [c_int, c_int, ctypes.c_float, c_void_p]),
@@ -396,3 +398,40 @@ def linear_relu_ln_forward(x2, weight, bias, gamma, beta, eps):
                                               stream_ptr(x2.device))
     check(st, "hipad_linear_relu_ln_forward")
     return y, xr, mean, rstd
+
+
+def box_points_project_forward(anchor, fix_scale, learn, projection_mat, image_wh, want_key_points=False):
+    """anchor (bs,A,D) -> loc (bs,A,P,cams,2) [+ key_points (bs,A,P,3)]; see include/hipad.h."""
+    lib = load()
+    _req(anchor, torch.float32, "anchor"); _req(fix_scale, torch.float32, "fix_scale")
+    _req(projection_mat, torch.float32, "projection_mat")
+    bs, A, D = anchor.shape
+    n_fix = fix_scale.shape[0]
+    n_learn = 0 if learn is None else learn.shape[-1] // 3
+    cams = projection_mat.shape[1]
+    P = n_fix + n_learn
+    loc = torch.empty(bs, A, P, cams, 2, dtype=torch.float32, device=anchor.device)
+    kp = torch.empty(bs, A, P, 3, dtype=torch.float32, device=anchor.device) if want_key_points else None
+    with torch.cuda.device(anchor.device):
+        st = lib.hipad_box_points_project_forward(loc.data_ptr(), _ptr(kp), anchor.data_ptr(), fix_scale.data_ptr(), _ptr(learn),
+                                                  projection_mat.data_ptr(), _ptr(image_wh), bs, A, n_fix, n_learn, cams, D,
+                                                  stream_ptr(anchor.device))
+    check(st, "hipad_box_points_project_forward")
+    return loc, kp
+
+
+def box_points_project_backward(grad_loc, anchor, fix_scale, learn, projection_mat, image_wh):
+    lib = load()
+    _req(grad_loc, torch.float32, "grad_loc")
+    bs, A, D = anchor.shape
+    n_fix = fix_scale.shape[0]
+    n_learn = 0 if learn is None else learn.shape[-1] // 3
+    cams = projection_mat.shape[1]
+    g_anchor = torch.empty_like(anchor)
+    g_learn = torch.empty_like(learn) if learn is not None else None
+    with torch.cuda.device(anchor.device):
+        st = lib.hipad_box_points_project_backward(g_anchor.data_ptr(), _ptr(g_learn), grad_loc.data_ptr(), anchor.data_ptr(),
+                                                   fix_scale.data_ptr(), _ptr(learn), projection_mat.data_ptr(), _ptr(image_wh),
+                                                   bs, A, n_fix, n_learn, cams, D, stream_ptr(anchor.device))
+    check(st, "hipad_box_points_project_backward")
+    return g_anchor, g_learn

@@ -214,6 +214,28 @@ int hipad_linear_backward(float *dx, float *dw, float *db, const float *dy, cons
                           const float *x, const float *weight, int M, int N, int K, hipad_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Key points of 3D-box queries, generated and projected into every camera in one launch
+ * (hip-ad_amd/csrc/keypoints.hip).
+ * Replaces: SparseBox3DKeyPointsGenerator.forward (reference models/det/blocks.py:183-224) chained with
+ *           DeformableFeatureAggregation.project_points + permute (models/blocks.py:216-225, 144-145).
+ *   anchor [bs, A, anchor_dim >= 8] = [x,y,z, log w,l,h, sin,cos, ...]; fix_scale [n_fix, 3]; learn [bs, A, n_learn*3]
+ *   (the learnable_fc output BEFORE the sigmoid; NULL when n_learn == 0); projection_mat [bs, cams, 4, 4];
+ *   image_wh [bs, cams, 2] or NULL -> loc [bs, A, n_fix + n_learn, cams, 2] (the aggregation op's layout);
+ *   key_points [bs, A, P, 3] is written too when not NULL.
+ *   backward: grad_anchor [bs, A, anchor_dim] OVERWRITTEN (zero-filled here, columns 0..7 accumulated), grad_learn
+ *   overwritten.
+ * ---------------------------------------------------------------------------------- */
+int hipad_box_points_project_forward(float *loc, float *key_points, const float *anchor, const float *fix_scale,
+                                     const float *learn, const float *projection_mat, const float *image_wh,
+                                     int batch_size, int num_anchors, int n_fix, int n_learn, int num_cams,
+                                     int anchor_dim, hipad_stream_t stream);
+int hipad_box_points_project_backward(float *grad_anchor, float *grad_learn, const float *grad_loc,
+                                      const float *anchor, const float *fix_scale, const float *learn,
+                                      const float *projection_mat, const float *image_wh, int batch_size,
+                                      int num_anchors, int n_fix, int n_learn, int num_cams, int anchor_dim,
+                                      hipad_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * LayerNorm over the last dimension (hip-ad_amd/csrc/layernorm.hip).
  * Replaces: nn.LayerNorm in the decoder -- linear_relu_ln stacks (reference models/blocks.py:32-42), the
  *           "norm" ops of the decoder program (projects/configs/hipad_b2d_stage2.py:293), AsymmetricFFN's

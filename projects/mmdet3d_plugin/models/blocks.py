@@ -135,9 +135,13 @@ class DeformableFeatureAggregation(BaseModule):
         # NB the reference passes (anchor, anchor_embed, instance_feature) positionally; the box
         # generator's second parameter is named instance_feature, so its learnable offsets are a
         # function of anchor_embed -- kept as is.
-        key_points = self.kps_generator(anchor, anchor_embed, instance_feature)
         weights = self._get_weights(instance_feature, anchor_embed, metas, op_layout=True)
-        loc = HF.project_points(key_points, metas["projection_mat"], metas.get("image_wh"))
+        if anchor.is_cuda and hasattr(self.kps_generator, "project"):
+            # generator + projection fused: the key points are never written to memory
+            loc = self.kps_generator.project(anchor, anchor_embed, metas["projection_mat"], metas.get("image_wh"))
+        else:
+            key_points = self.kps_generator(anchor, anchor_embed, instance_feature)
+            loc = HF.project_points(key_points, metas["projection_mat"], metas.get("image_wh"))
         features = DAF(*feature_maps, loc, weights).reshape(bs, num_anchor, self.embed_dims)
         output = self.proj_drop(self.output_proj(features))
         if self.residual_mode == "add":

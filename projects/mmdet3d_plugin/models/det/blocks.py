@@ -143,6 +143,18 @@ class SparseBox3DKeyPointsGenerator(BaseModule):
             warped.append((T[..., :3, :3] @ pts[..., None]).squeeze(-1) + T[..., :3, 3])
         return key_points, warped
 
+    def project(self, anchor, instance_feature, projection_mat, image_wh=None):
+        """Key points of ``forward`` projected into every camera, in the aggregation op's location layout
+        (bs, A, num_pts, cams, 2) -- ONE kernel (hipad_box_points_project_*) instead of this module's ~15 elementwise
+        kernels plus the projection; used by DeformableFeatureAggregation when the inputs are on the GPU."""
+        from hipad_amd import functional as HF
+        learn = None
+        if self.num_learnable_pts > 0 and instance_feature is not None:
+            learn = self.learnable_fc(instance_feature)
+        elif self.num_learnable_pts > 0:
+            raise ValueError("learnable key points need the instance feature")
+        return HF.box_points_project(anchor, self.fix_scale, learn, projection_mat, image_wh)
+
     @staticmethod
     def anchor_projection(anchor, T_src2dst_list, src_timestamp=None, dst_timestamps=None, time_intervals=None):
         """Move box anchors from one ego frame to others (reference det/blocks.py:250-296)."""

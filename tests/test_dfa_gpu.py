@@ -180,3 +180,42 @@ def test_dfa_module_trains(golden):
     assert anchor.grad is not None and anchor.grad.abs().sum() > 0
     assert all(m.grad is not None and torch.isfinite(m.grad).all() for m in maps)
     assert sum(float(m.grad.abs().sum()) for m in maps) > 0
+
+
+@pytest.mark.parametrize("A,n_learn", [(900, 6), (1, 12), (37, 0)])
+def test_box_key_points_projection_fused_equals_chain(A, n_learn):
+    """hipad_box_points_project_* against the module's own two-step path (SparseBox3DKeyPointsGenerator.forward in torch
+    ops, then the bit-exact projection kernel): locations to 1e-6 of the image size, gradients w.r.t. anchor and the
+    learnable-offset layer to 1e-4."""
+    import projects.mmdet3d_plugin.models  # noqa: F401
+    from hipad_amd import functional as HF
+    from hipad_amd import synthetic as syn
+    from projects.mmdet3d_plugin.models.det.blocks import SparseBox3DKeyPointsGenerator
+    torch.manual_seed(A + n_learn)
+    fix = [[0, 0, 0], [0.45, 0, 0], [-0.45, 0, 0], [0, 0.45, 0], [0, -0.45, 0], [0, 0, 0.45], [0, 0, -0.45]]
+    gen = SparseBox3DKeyPointsGenerator(256, num_learnable_pts=n_learn, fix_scale=fix).cuda()
+    gen.init_weight()
+    pm, wh = syn.projection_mats((256, 704), bs=2)
+    pm, wh = torch.from_numpy(pm).cuda(), torch.from_numpy(wh).cuda()
+    anchor = torch.randn(2, A, 11).cuda()
+    anchor[..., :3] *= torch.tensor([12.0, 25.0, 1.5]).cuda()
+    anchor[..., 3:6] = anchor[..., 3:6] * 0.3 + 0.8
+    feat = torch.randn(2, A, 256).cuda()
+    a1, f1 = anchor.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+    a2, f2 = anchor.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+    loc_fused = gen.project(a1, f1, pm, wh)
+    loc_chain = HF.project_points(gen(a2, f2), pm, wh)
+    assert loc_fused.shape == loc_chain.shape == (2, A, 7 + n_learn, 6, 2)
+    visible = (loc_chain.abs() < 3).all(-1)            # in front of the camera, near the image: well conditioned
+    assert float((loc_fused - loc_chain).abs()[visible].max()) < 1e-5
+    go = torch.randn_like(loc_chain) * visible[..., None]
+    gen.zero_grad()
+    loc_fused.backward(go)
+    gw1 = None if n_learn == 0 else gen.learnable_fc.weight.grad.clone()
+    gen.zero_grad()
+    loc_chain.backward(go)
+    scale = float(a2.grad.abs().max())
+    assert float((a1.grad - a2.grad).abs().max()) < 1e-4 * scale
+    if n_learn:
+        assert float((f1.grad - f2.grad).abs().max()) < 2e-2 * float(f2.grad.abs().max())   # through the bf16-operand Linear
+        assert float((gw1 - gen.learnable_fc.weight.grad).abs().max()) < 2e-2 * float(gw1.abs().max())
