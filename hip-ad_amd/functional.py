@@ -350,3 +350,26 @@ def box_points_project(anchor, fix_scale, learn, projection_mat, image_wh=None):
     """Box key points (fixed + learnable offsets, yaw rotation, translation) projected into every camera:
     (bs,A,D) anchors, (n_fix,3) scales, (bs,A,n_learn*3) pre-sigmoid logits or None -> loc (bs,A,P,cams,2)."""
     return _BoxPointsProject.apply(anchor, fix_scale, learn, projection_mat, image_wh)
+
+
+class _LinePointsProject(Function):
+    @staticmethod
+    def forward(ctx, anchor, offset, heights, projection_mat, image_wh, S, Hn, K):
+        an, of, hs, pm, wh = _c32(anchor), _c32(offset), _c32(heights), _c32(projection_mat), _c32(image_wh)
+        ctx.save_for_backward(an, of, hs, pm, wh)
+        ctx.dims = (S, Hn, K)
+        return _lib.line_points_project_forward(an, of, hs, pm, wh, S, Hn, K)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_loc):
+        an, of, hs, pm, wh = ctx.saved_tensors
+        g_anchor, g_offset = _lib.line_points_project_backward(_c32(grad_loc), an, of, hs, pm, wh, *ctx.dims)
+        return g_anchor, g_offset, None, None, None, None, None, None
+
+
+def line_points_project(anchor, offset, heights, projection_mat, image_wh, num_sample, num_heights, num_learnable):
+    """Poly-line key points (sample + learned planar offset, at every height) projected into every camera:
+    anchor (bs,A,S*2), offset (bs,A,S*Hn*K*2), heights (Hn,) -> loc (bs,A,S*Hn*K,cams,2)."""
+    return _LinePointsProject.apply(anchor, offset, heights, projection_mat, image_wh, int(num_sample), int(num_heights),
+                                    int(num_learnable))

@@ -32,6 +32,8 @@ SIGNATURES = {
     "hipad_linear_backward": (c_int, [c_void_p] * 7 + [c_int] * 3 + [c_void_p]),
     "hipad_box_points_project_forward": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_void_p]),
     "hipad_box_points_project_backward": (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_void_p]),
+    "hipad_line_points_project_forward": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p]),
+    "hipad_line_points_project_backward": (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_void_p]),
     "hipad_linear_relu_ln_supported": (c_int, [c_int, c_int]),
     "hipad_linear_relu_ln_forward": (c_int, [c_void_p] * 9 + [c_int] * 3 + [ctypes.c_float, c_void_p]),
     "hipad_layernorm_forward": (c_int, [c_void_p] * 6 + [c_int, c_int, ctypes.c_float, c_void_p]),
@@ -435,3 +437,33 @@ def box_points_project_backward(grad_loc, anchor, fix_scale, learn, projection_m
                                                    bs, A, n_fix, n_learn, cams, D, stream_ptr(anchor.device))
     check(st, "hipad_box_points_project_backward")
     return g_anchor, g_learn
+
+
+def line_points_project_forward(anchor, offset, heights, projection_mat, image_wh, S, Hn, K):
+    lib = load()
+    for t, n in ((anchor, "anchor"), (offset, "offset"), (heights, "heights"), (projection_mat, "projection_mat")):
+        _req(t, torch.float32, n)
+    bs, A = anchor.shape[:2]
+    cams = projection_mat.shape[1]
+    loc = torch.empty(bs, A, S * Hn * K, cams, 2, dtype=torch.float32, device=anchor.device)
+    with torch.cuda.device(anchor.device):
+        st = lib.hipad_line_points_project_forward(loc.data_ptr(), anchor.data_ptr(), offset.data_ptr(), heights.data_ptr(),
+                                                   projection_mat.data_ptr(), _ptr(image_wh), bs, A, S, Hn, K, cams,
+                                                   stream_ptr(anchor.device))
+    check(st, "hipad_line_points_project_forward")
+    return loc
+
+
+def line_points_project_backward(grad_loc, anchor, offset, heights, projection_mat, image_wh, S, Hn, K):
+    lib = load()
+    _req(grad_loc, torch.float32, "grad_loc")
+    bs, A = anchor.shape[:2]
+    cams = projection_mat.shape[1]
+    g_anchor, g_offset = torch.empty_like(anchor), torch.empty_like(offset)
+    with torch.cuda.device(anchor.device):
+        st = lib.hipad_line_points_project_backward(g_anchor.data_ptr(), g_offset.data_ptr(), grad_loc.data_ptr(),
+                                                    anchor.data_ptr(), offset.data_ptr(), heights.data_ptr(),
+                                                    projection_mat.data_ptr(), _ptr(image_wh), bs, A, S, Hn, K, cams,
+                                                    stream_ptr(anchor.device))
+    check(st, "hipad_line_points_project_backward")
+    return g_anchor, g_offset

@@ -235,6 +235,19 @@ int hipad_box_points_project_backward(float *grad_anchor, float *grad_learn, con
                                       int num_anchors, int n_fix, int n_learn, int num_cams, int anchor_dim,
                                       hipad_stream_t stream);
 
+/* Same for poly-line queries (map elements, plan trajectories): SparsePoint3DKeyPointsGenerator.forward (reference
+ * models/map/blocks.py:172-225) + projection.  anchor [bs, A, num_sample*2]; offset [bs, A, num_sample*num_heights*
+ * num_learnable*2] (the learnable_fc output); heights [num_heights] (ground_height + fix_height) ->
+ * loc [bs, A, num_sample*num_heights*num_learnable, cams, 2].  backward overwrites grad_anchor and grad_offset. */
+int hipad_line_points_project_forward(float *loc, const float *anchor, const float *offset, const float *heights,
+                                      const float *projection_mat, const float *image_wh, int batch_size,
+                                      int num_anchors, int num_sample, int num_heights, int num_learnable, int num_cams,
+                                      hipad_stream_t stream);
+int hipad_line_points_project_backward(float *grad_anchor, float *grad_offset, const float *grad_loc, const float *anchor,
+                                       const float *offset, const float *heights, const float *projection_mat,
+                                       const float *image_wh, int batch_size, int num_anchors, int num_sample,
+                                       int num_heights, int num_learnable, int num_cams, hipad_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * LayerNorm over the last dimension (hip-ad_amd/csrc/layernorm.hip).
  * Replaces: nn.LayerNorm in the decoder -- linear_relu_ln stacks (reference models/blocks.py:32-42), the

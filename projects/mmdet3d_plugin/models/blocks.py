@@ -136,9 +136,13 @@ class DeformableFeatureAggregation(BaseModule):
         # generator's second parameter is named instance_feature, so its learnable offsets are a
         # function of anchor_embed -- kept as is.
         weights = self._get_weights(instance_feature, anchor_embed, metas, op_layout=True)
-        if anchor.is_cuda and hasattr(self.kps_generator, "project"):
-            # generator + projection fused: the key points are never written to memory
-            loc = self.kps_generator.project(anchor, anchor_embed, metas["projection_mat"], metas.get("image_wh"))
+        fused = anchor.is_cuda and hasattr(self.kps_generator, "project") and not getattr(self.kps_generator, "with_points_embed", False)
+        if fused:
+            # generator + projection fused: the key points are never written to memory.  (Positional call like the
+            # reference: the box generator's second parameter receives anchor_embed, the poly-line generator's
+            # second and third receive anchor_embed and instance_feature.)
+            extra = (anchor_embed,) if self.kps_generator.project.__code__.co_argcount == 5 else (anchor_embed, instance_feature)
+            loc = self.kps_generator.project(anchor, *extra, metas["projection_mat"], metas.get("image_wh"))
         else:
             key_points = self.kps_generator(anchor, anchor_embed, instance_feature)
             loc = HF.project_points(key_points, metas["projection_mat"], metas.get("image_wh"))

@@ -136,6 +136,17 @@ class SparsePoint3DKeyPointsGenerator(BaseModule):
             warped.append((T[..., :3, :3] @ key_points[..., None]).squeeze(-1) + T[..., :3, 3])
         return key_points, warped
 
+    def project(self, anchor, anchor_embed, instance_feature, projection_mat, image_wh=None):
+        """Key points of ``forward`` projected into every camera in the aggregation op's layout
+        (bs, A, num_pts, cams, 2): the Linear, then ONE kernel (hipad_line_points_project_*)."""
+        from hipad_amd import functional as HF
+        if self.num_learnable_pts <= 0 or self.with_points_embed:
+            raise NotImplementedError("fused projection covers the configuration the HiP-AD configs use")
+        src = instance_feature + anchor_embed if self.with_anchor_embed else instance_feature
+        offset = self.learnable_fc(src)
+        return HF.line_points_project(anchor, offset, self._height_levels, projection_mat, image_wh, self.num_sample,
+                                      len(self.fix_height), self.num_learnable_pts)
+
     def anchor_projection(self, anchor, T_src2dst_list, src_timestamp=None, dst_timestamps=None, time_intervals=None):
         """Move the (x, y) samples of each poly-line into other ego frames (reference map/blocks.py:227-265)."""
         moved = []

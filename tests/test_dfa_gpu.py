@@ -219,3 +219,34 @@ def test_box_key_points_projection_fused_equals_chain(A, n_learn):
     if n_learn:
         assert float((f1.grad - f2.grad).abs().max()) < 2e-2 * float(f2.grad.abs().max())   # through the bf16-operand Linear
         assert float((gw1 - gen.learnable_fc.weight.grad).abs().max()) < 2e-2 * float(gw1.abs().max())
+
+
+@pytest.mark.parametrize("A,S,K", [(100, 20, 3), (480, 6, 3), (3, 5, 2)])
+def test_line_key_points_projection_fused_equals_chain(A, S, K):
+    """hipad_line_points_project_* against SparsePoint3DKeyPointsGenerator.forward (torch ops) + the projection kernel."""
+    import projects.mmdet3d_plugin.models  # noqa: F401
+    from hipad_amd import functional as HF
+    from hipad_amd import synthetic as syn
+    from projects.mmdet3d_plugin.models.map.blocks import SparsePoint3DKeyPointsGenerator
+    torch.manual_seed(A + S)
+    heights = (0.0, 0.5, -0.5, 1.0, -1.0)
+    gen = SparsePoint3DKeyPointsGenerator(256, num_sample=S, num_learnable_pts=K, fix_height=heights, ground_height=-1.84023,
+                                          with_anchor_embed=True).cuda()
+    gen.init_weight()
+    pm, wh = syn.projection_mats((256, 704), bs=2)
+    pm, wh = torch.from_numpy(pm).cuda(), torch.from_numpy(wh).cuda()
+    anchor = (torch.randn(2, A, S * 2) * 12).cuda()
+    embed, feat = torch.randn(2, A, 256).cuda(), torch.randn(2, A, 256).cuda()
+    a1, a2 = anchor.clone().requires_grad_(True), anchor.clone().requires_grad_(True)
+    f1, f2 = feat.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+    loc_fused = gen.project(a1, embed, f1, pm, wh)
+    loc_chain = HF.project_points(gen(a2, embed, f2), pm, wh)
+    assert loc_fused.shape == loc_chain.shape == (2, A, S * len(heights) * K, 6, 2)
+    visible = (loc_chain.abs() < 3).all(-1)
+    assert float((loc_fused - loc_chain).abs()[visible].max()) < 1e-5
+    go = torch.randn_like(loc_chain) * visible[..., None]
+    loc_fused.backward(go)
+    gen.zero_grad()
+    loc_chain.backward(go)
+    assert float((a1.grad - a2.grad).abs().max()) < 1e-4 * float(a2.grad.abs().max())
+    assert float((f1.grad - f2.grad).abs().max()) < 2e-2 * float(f2.grad.abs().max())
