@@ -373,3 +373,27 @@ def line_points_project(anchor, offset, heights, projection_mat, image_wh, num_s
     anchor (bs,A,S*2), offset (bs,A,S*Hn*K*2), heights (Hn,) -> loc (bs,A,S*Hn*K,cams,2)."""
     return _LinePointsProject.apply(anchor, offset, heights, projection_mat, image_wh, int(num_sample), int(num_heights),
                                     int(num_learnable))
+
+
+class _FocalLoss(Function):
+    @staticmethod
+    def forward(ctx, logits, target, weight, avg_factor, layers, alpha, gamma):
+        x = _c32(logits)
+        w = None if weight is None else _c32(weight.to(torch.float32))
+        a = None if avg_factor is None else _c32(avg_factor.to(torch.float32).reshape(-1).expand(layers))
+        loss, grad = _lib.focal_loss_forward(x, target.contiguous(), w, a, layers, alpha, gamma)
+        ctx.save_for_backward(grad)
+        ctx.layers = layers
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_loss):
+        (grad,) = ctx.saved_tensors
+        g = grad.view(ctx.layers, -1) * grad_loss.reshape(ctx.layers, 1)
+        return g.view_as(grad), None, None, None, None, None, None
+
+
+def focal_loss(logits, target, weight=None, avg_factor=None, layers=1, alpha=0.25, gamma=2.0):
+    """Per-layer sigmoid focal loss (see include/hipad.h): logits (rows, C), integer targets in [0, C] -> (layers,)."""
+    return _FocalLoss.apply(logits, target, weight, avg_factor, int(layers), float(alpha), float(gamma))

@@ -39,6 +39,7 @@ SIGNATURES = {
     "hipad_layernorm_forward": (c_int, [c_void_p] * 6 + [c_int, c_int, ctypes.c_float, c_void_p]),
     "hipad_layernorm_backward": (c_int, [c_void_p] * 8 + [c_int, c_int, c_void_p]),
     "hipad_linear_assignment": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
+    "hipad_focal_loss_forward": (c_int, [c_void_p] * 6 + [ctypes.c_longlong, c_int, c_int, ctypes.c_float, ctypes.c_float, c_void_p]),
     "hipad_adamw_workspace": (c_size_t, []),
     "hipad_adamw_step": (c_int, [c_void_p] * 4 + [ctypes.c_longlong] * 2 + [ctypes.c_float] * 7
                          + [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
@@ -467,3 +468,18 @@ def line_points_project_backward(grad_loc, anchor, offset, heights, projection_m
                                                     stream_ptr(anchor.device))
     check(st, "hipad_line_points_project_backward")
     return g_anchor, g_offset
+
+
+def focal_loss_forward(logits, target, weight, avg_factor, layers, alpha, gamma):
+    """logits (rows, C) fp32, target (rows,) int64 -> loss_per_layer (layers,), grad_logits (rows, C)."""
+    lib = load()
+    _req(logits, torch.float32, "logits"); _req(target, torch.int64, "target")
+    rows, C = logits.shape
+    loss = torch.empty(layers, dtype=torch.float32, device=logits.device)
+    grad = torch.empty_like(logits)
+    with torch.cuda.device(logits.device):
+        st = lib.hipad_focal_loss_forward(loss.data_ptr(), grad.data_ptr(), logits.data_ptr(), target.data_ptr(), _ptr(weight),
+                                          _ptr(avg_factor), rows, C, int(layers), float(alpha), float(gamma),
+                                          stream_ptr(logits.device))
+    check(st, "hipad_focal_loss_forward")
+    return loss, grad

@@ -281,6 +281,20 @@ int hipad_linear_assignment(int *col_of_row, const float *cost, const int *n_row
                             int cols, hipad_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Sigmoid focal loss, value and logit gradient in one pass (hip-ad_amd/csrc/losses.hip).
+ * Replaces: mmdet==2.28.2 FocalLoss(use_sigmoid=True) as called by the reference's loss()
+ *           (models/sparse_onedecoder.py:1146, 1201, 1302, 1360-1362).
+ *   logits [rows, num_classes] f32; target [rows] int64 in [0, num_classes] (num_classes = background);
+ *   weight [rows] or NULL; rows are layer-major, `layers` equal groups; avg_factor [layers] or NULL.
+ *   loss_per_layer [layers] (out) = sum over the group of loss * weight / (avg_factor[l] + eps), or the group mean
+ *   when avg_factor is NULL (mmdet's weight_reduce_loss, reduction 'mean'); grad_logits [rows, num_classes] (out)
+ *   = d loss_per_layer[l(row)] / d logits.
+ * ---------------------------------------------------------------------------------- */
+int hipad_focal_loss_forward(float *loss_per_layer, float *grad_logits, const float *logits, const long long *target,
+                             const float *weight, const float *avg_factor, long long rows, int num_classes,
+                             int layers, float alpha, float gamma, hipad_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Gradient clipping + AdamW over flat buffers (hip-ad_amd/csrc/optim.hip).
  * Replaces: the per-tensor optimiser step of the reference's training loop: mmcv OptimizerHook
  *           grad_clip (max_norm 25) + torch.optim.AdamW with the backbone at lr x0.5

@@ -89,6 +89,10 @@ class FocalLoss(nn.Module):
         self.gamma, self.alpha, self.loss_weight = gamma, alpha, loss_weight
 
     def forward(self, pred, target, weight=None, avg_factor=None, layers=1):
+        if pred.is_cuda and pred.dim() == 2 and pred.dtype == torch.float32:
+            from hipad_amd import functional as HF  # value + logit gradient in one kernel
+            loss = HF.focal_loss(pred, target, weight, avg_factor, layers, self.alpha, self.gamma)
+            return self.loss_weight * (loss.reshape(()) if layers == 1 else loss)
         c = pred.shape[-1]
         t = F.one_hot(target, c + 1)[..., :c].to(pred.dtype)
         p = pred.sigmoid()
