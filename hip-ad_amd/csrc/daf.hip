@@ -52,8 +52,11 @@ int fill_zero(void *ptr, size_t bytes, hipStream_t stream) {
 // grid = ceil(n_items / 4) blocks of 256 threads; one wave per item.
 // dst = out (nchunks == 1) or partial slabs [n_items, 256] (nchunks > 1).
 // =====================================================================================
-template <int LT>  // LT = compile-time number of levels (0 = runtime)
-__global__ __launch_bounds__(256) void daf_fwd_c256_kernel(
+// LT = compile-time number of levels (0 = runtime).  GEO: (height, width, first row) of every (camera, level) held in
+// lanes 0..cams*L-1 and read back with v_readlane -- no scalar memory load between a pair's coordinates and its row
+// loads (needs cams*L <= 64).
+template <int LT, bool GEO>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void daf_fwd_c256_kernel(
     float *__restrict__ dst, const float *__restrict__ feat, const int *__restrict__ ss,
     const int *__restrict__ start, const float *__restrict__ loc, const float *__restrict__ wts,
     int n_items, int nchunks, int ppc, int cams, int num_feat, int L_rt, int A, int P, int G) {
@@ -76,6 +79,13 @@ __global__ __launch_bounds__(256) void daf_fwd_c256_kernel(
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   const float *wbase = wts + (size_t)it.pair0 * L * G + g;
   const size_t frow0 = (size_t)it.b * num_feat;  // first pyramid row of this sample
+  int geoH = 1, geoW = 1, geoS = 0;
+  if (GEO && lane < cams * L) {
+    geoH = ss[2 * lane];
+    geoW = ss[2 * lane + 1];
+    geoS = start[lane];
+  }
+  asm volatile("" : "+v"(geoH), "+v"(geoW), "+v"(geoS));  // the loads land here, not inside the pair loop
 
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -91,12 +101,12 @@ __global__ __launch_bounds__(256) void daf_fwd_c256_kernel(
 #pragma unroll
       for (int s = 0; s < L; ++s) {
         const int cs = cam * L + s;
-        const int H = ss[2 * cs], W = ss[2 * cs + 1];
+        const int H = GEO ? rl_i(geoH, cs) : ss[2 * cs], W = GEO ? rl_i(geoW, cs) : ss[2 * cs + 1];
         const Taps t = make_taps(loc_h, loc_w, H, W);
         // rows clamped into the map so every load is legal; out-of-map corners are zeroed
         const int h0 = max(t.h_low, 0), h1 = min(t.h_low + 1, H - 1);
         const int w0 = max(t.w_low, 0), w1 = min(t.w_low + 1, W - 1);
-        const size_t base = frow0 + (size_t)start[cs];
+        const size_t base = frow0 + (size_t)(GEO ? rl_i(geoS, cs) : start[cs]);
         const float4 *r00 = reinterpret_cast<const float4 *>(feat + (base + (size_t)uni(h0 * W + w0)) * 256) + lane;
         const float4 *r01 = reinterpret_cast<const float4 *>(feat + (base + (size_t)uni(h0 * W + w1)) * 256) + lane;
         const float4 *r10 = reinterpret_cast<const float4 *>(feat + (base + (size_t)uni(h1 * W + w0)) * 256) + lane;
@@ -556,18 +566,19 @@ int hipad_daf_forward(float *out, const float *feat, const int32_t *spatial_shap
   const bool fast = (C == 256) && ((C / G) % 4 == 0);
   if (fast) {
     const int blocks = (n_items + 3) / 4;
-    if (L == 4)
-      hipLaunchKernelGGL(daf_fwd_c256_kernel<4>, dim3(blocks), dim3(256), 0, stream, dst, feat,
-                         spatial_shape, scale_start_index, loc, weights, n_items, pl.nchunks, pl.ppc,
-                         cams, num_feat, L, A, P, G);
-    else if (L == 1)
-      hipLaunchKernelGGL(daf_fwd_c256_kernel<1>, dim3(blocks), dim3(256), 0, stream, dst, feat,
-                         spatial_shape, scale_start_index, loc, weights, n_items, pl.nchunks, pl.ppc,
-                         cams, num_feat, L, A, P, G);
-    else
-      hipLaunchKernelGGL(daf_fwd_c256_kernel<0>, dim3(blocks), dim3(256), 0, stream, dst, feat,
-                         spatial_shape, scale_start_index, loc, weights, n_items, pl.nchunks, pl.ppc,
-                         cams, num_feat, L, A, P, G);
+#define HIPAD_FWD(LT, GEO)                                                                                  \
+  hipLaunchKernelGGL((daf_fwd_c256_kernel<LT, GEO>), dim3(blocks), dim3(256), 0, stream, dst, feat,         \
+                     spatial_shape, scale_start_index, loc, weights, n_items, pl.nchunks, pl.ppc, cams,     \
+                     num_feat, L, A, P, G)
+    const bool geo = cams * L <= kWave;
+    if (L == 4) {
+      if (geo) HIPAD_FWD(4, true); else HIPAD_FWD(4, false);
+    } else if (L == 1) {
+      if (geo) HIPAD_FWD(1, true); else HIPAD_FWD(1, false);
+    } else {
+      if (geo) HIPAD_FWD(0, true); else HIPAD_FWD(0, false);
+    }
+#undef HIPAD_FWD
     if (pl.nchunks > 1) {
       const int n = n_anchor * 64;
       hipLaunchKernelGGL(daf_fwd_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, out,

@@ -296,14 +296,13 @@ __global__ __launch_bounds__(256) void daf_bwd_feat_kernel(
 // ------------------------------------------------------------------------------------------
 // 5: grad_weights + grad_location.  C == 256, G == 8, one wave per item, float4 per lane.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float group8_sum(float v) {
-  v += __shfl_xor(v, 1);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 4);
-  return v;
-}
+__device__ __forceinline__ float group8_sum(float v) { return oct_sum(v); }
 
-template <int LT, bool OVERWRITE>
+// GEO: the (height, width, first row) of every (camera, level) sits in lanes 0..cams*L-1 and is read back with
+// v_readlane, so the pair loop has no scalar memory load between a pair's coordinates and its 16 row loads.  The loop
+// body is branch-free (null gw / gloc only skip the final stores): with uniform branches between the levels the
+// compiler kept each level's loads behind the previous level's reduction, four memory latencies per pair instead of one.
+template <int LT, bool OVERWRITE, bool GEO>
 __global__ __launch_bounds__(256) void daf_bwd_lw_kernel(
     const float *__restrict__ feat, const int *__restrict__ ss, const int *__restrict__ start,
     const float *__restrict__ loc, const float *__restrict__ wts, const float *__restrict__ gout,
@@ -346,6 +345,15 @@ __global__ __launch_bounds__(256) void daf_bwd_lw_kernel(
   const int g = lane >> 3;
   const float *wbase = wts + (size_t)it.pair0 * L * G + g;
   const size_t frow0 = (size_t)it.b * num_feat;
+  int geoH = 1, geoW = 1, geoS = 0;
+  if (GEO && lane < cams * L) {
+    geoH = ss[2 * lane];
+    geoW = ss[2 * lane + 1];
+    geoS = start[lane];
+  }
+  // land the loads above here (an empty asm that consumes the registers): left pending, the compiler's wait for them
+  // sits inside the pair loop, where it is also a wait for the previous pair's stores
+  asm volatile("" : "+v"(geoH), "+v"(geoW), "+v"(geoS));
 
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -360,14 +368,19 @@ __global__ __launch_bounds__(256) void daf_bwd_lw_kernel(
       const size_t wofs = (size_t)pidx * L * G;
       float gl_w = 0.f, gl_h = 0.f;
       float keep = 0.f;  // lane (g, s = lane & 7) keeps the reduced grad_w of level s
+      // the pair's sampling weights first: issued after the row loads, the wait for the last of them is a wait for
+      // everything outstanding, this pair's grad_w store included
+      float awl[LT ? LT : 1];
+#pragma unroll
+      for (int s = 0; s < LT; ++s) awl[s] = wbase[wofs + s * G];
 #pragma unroll
       for (int s = 0; s < L; ++s) {
         const int cs = cam * L + s;
-        const int H = ss[2 * cs], W = ss[2 * cs + 1];
+        const int H = GEO ? rl_i(geoH, cs) : ss[2 * cs], W = GEO ? rl_i(geoW, cs) : ss[2 * cs + 1];
         const Taps t = make_taps(loc_h, loc_w, H, W);
         const int h0 = max(t.h_low, 0), h1 = min(t.h_low + 1, H - 1);
         const int w0 = max(t.w_low, 0), w1 = min(t.w_low + 1, W - 1);
-        const size_t base = frow0 + (size_t)start[cs];
+        const size_t base = frow0 + (size_t)(GEO ? rl_i(geoS, cs) : start[cs]);
         const float4 *r00 = reinterpret_cast<const float4 *>(feat + (base + (size_t)uni(h0 * W + w0)) * 256) + lane;
         const float4 *r01 = reinterpret_cast<const float4 *>(feat + (base + (size_t)uni(h0 * W + w1)) * 256) + lane;
         const float4 *r10 = reinterpret_cast<const float4 *>(feat + (base + (size_t)uni(h1 * W + w0)) * 256) + lane;
@@ -376,7 +389,7 @@ __global__ __launch_bounds__(256) void daf_bwd_lw_kernel(
         const float4 v2 = sel4(t.in_h0 && t.in_w1, *r01);
         const float4 v3 = sel4(t.in_h1 && t.in_w0, *r10);
         const float4 v4 = sel4(t.in_h1 && t.in_w1, *r11);
-        const float aw = wbase[wofs + s * G];
+        const float aw = LT ? awl[LT ? s : 0] : wbase[wofs + s * G];
         const float w1c = t.hh * t.hw, w2c = t.hh * t.lw, w3c = t.lh * t.hw, w4c = t.lh * t.lw;
         // value, d/dh, d/dw per channel (cu:92-118), dotted with grad_out
         float dot_val, dot_h, dot_w;
@@ -399,10 +412,8 @@ __global__ __launch_bounds__(256) void daf_bwd_lw_kernel(
         }
         gl_w += (float)W * aw * dot_w;  // cu:124 with top = grad_out * weight
         gl_h += (float)H * aw * dot_h;  // cu:125
-        if (gw) {
-          const float gs = group8_sum(dot_val);  // cu:122 summed over the group's 32 channels
-          keep = ((lane & 7) == s) ? gs : keep;
-        }
+        const float gs = group8_sum(dot_val);  // cu:122 summed over the group's 32 channels
+        keep = ((lane & 7) == s) ? gs : keep;
       }
       if (gw) {
         if (L <= 8) {
@@ -493,14 +504,19 @@ int daf_bwd_lw(const float *feat, const int *ss, const int *start, const float *
                bool overwrite, hipStream_t stream) {
   const int n_items = d.bs * d.A * nchunks;
   const int blocks = (n_items + 3) / 4;
-#define HIPAD_LW(LT, OW)                                                                          \
-  hipLaunchKernelGGL((daf_bwd_lw_kernel<LT, OW>), dim3(blocks), dim3(256), 0, stream, feat, ss,   \
-                     start, loc, wts, gout, gloc, gw, n_items, nchunks, ppc, d.cams, d.num_feat,  \
+#define HIPAD_LW(LT, OW, GEO)                                                                         \
+  hipLaunchKernelGGL((daf_bwd_lw_kernel<LT, OW, GEO>), dim3(blocks), dim3(256), 0, stream, feat, ss,  \
+                     start, loc, wts, gout, gloc, gw, n_items, nchunks, ppc, d.cams, d.num_feat,      \
                      d.L, d.A, d.P)
-  if (d.L == 4) {
-    if (overwrite) HIPAD_LW(4, true); else HIPAD_LW(4, false);
+  const bool geo = d.cams * d.L <= kWave;
+  if (d.L == 4 && geo) {
+    if (overwrite) HIPAD_LW(4, true, true); else HIPAD_LW(4, false, true);
+  } else if (d.L == 4) {
+    if (overwrite) HIPAD_LW(4, true, false); else HIPAD_LW(4, false, false);
+  } else if (geo) {
+    if (overwrite) HIPAD_LW(0, true, true); else HIPAD_LW(0, false, true);
   } else {
-    if (overwrite) HIPAD_LW(0, true); else HIPAD_LW(0, false);
+    if (overwrite) HIPAD_LW(0, true, false); else HIPAD_LW(0, false, false);
   }
 #undef HIPAD_LW
   return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;

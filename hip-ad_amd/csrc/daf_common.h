@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "wave_ops.h"
+
 namespace hipad {
 
 constexpr int kWave = 64;
@@ -46,12 +48,6 @@ __device__ __forceinline__ Taps make_taps(float loc_h, float loc_w, int H, int W
   return t;
 }
 
-__device__ __forceinline__ float rl_f(float v, int lane) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-__device__ __forceinline__ int rl_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
 __device__ __forceinline__ float4 sel4(bool c, float4 v) {
   return c ? v : make_float4(0.f, 0.f, 0.f, 0.f);
 }
@@ -76,20 +72,6 @@ __device__ __forceinline__ Item make_item(int item, int nchunks, int ppc, int ca
   return it;
 }
 
-
-__device__ __forceinline__ float half_wave_sum(float v) {
-  // sum over the 32 lanes of this lane's half; every lane of the half gets the result
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 8);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 1);
-  return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-  v = half_wave_sum(v);
-  return v + __shfl_xor(v, 32);
-}
 
 // Zero fill as a kernel: the library never uses hipMemsetAsync -- inside a captured hipGraph every node
 // is then a kernel node in one dependency chain (memset nodes were the one graph-node type only this

@@ -13,16 +13,13 @@
 #include <stdint.h>
 
 #include "hipad.h"
+#include "wave_ops.h"
 
 namespace hipad {
 
 constexpr int kLnMaxJ = 4;  // N <= 1024
 
-__device__ __forceinline__ float wave_sum64(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
+__device__ __forceinline__ float wave_sum64(float v) { return wave_sum(v); }  // DPP, wave-uniform (wave_ops.h)
 
 template <int J>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(float *__restrict__ y, float *__restrict__ mean_out,

@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "libhipad.so")
+SO_PATH = os.environ.get("HIPAD_LIB") or os.path.join(_HERE, "csrc", "libhipad.so")  # HIPAD_LIB: another build of the same ABI (A/B timing)
 
 c_int, c_void_p, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
 
@@ -115,6 +115,11 @@ _ws_cache = {}
 def _workspace(nbytes, device):
     """Grow-only scratch per (device, stream): calls on one stream are serialised and may share it, calls issued
     on different streams (the decoder runs its modality branches concurrently) must not."""
+    if torch.cuda.is_current_stream_capturing():
+        # memory handed out during a capture belongs to that graph's private pool: caching it under the stream handle
+        # would outlive the graph (torch recycles stream handles) and hand a later caller freed memory.  A fresh
+        # buffer per call is the usual captured-temporary pattern: the pool reuses the block for the next call.
+        return torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
