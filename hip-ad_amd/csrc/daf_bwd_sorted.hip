@@ -48,7 +48,9 @@ namespace hipad {
 // level first while every camera's map of that level still fits the table.
 // ------------------------------------------------------------------------------------------
 constexpr int kTapBlock = 1024;
-constexpr int kLdsRows = 14336;  // 56 KiB of counters (static LDS kept under 64 KiB: see DESIGN.md, graph replay)
+constexpr int kLdsRows = 24576;  // 96 KiB of counters: all four levels of the six 704x256 cameras (22 440 rows).  With the
+                                 // finest level left to global atomics the plan call's taps -- clustered on a few hundred
+                                 // rows of the front camera -- serialise in L2: 105 + 83 us per call instead of 42 + 37
 constexpr int kMaxMaps = 64;     // cams * L handled by the LDS path
 
 template <bool PLACE>
@@ -58,27 +60,42 @@ __global__ __launch_bounds__(kTapBlock) void daf_tap_pass_kernel(
     int npair, int cams, int num_feat, int L, int PA /* P*cams*A */, int cap /* slots in taps[] */) {
   __shared__ int tab[kLdsRows];
   __shared__ int map_base[kMaxMaps];  // LDS slot of the map's first row, or -1
-  __shared__ int used_s;
+  // geometry of every (camera, level) map, fetched once by nmaps threads in parallel: thread 0's slot assignment,
+  // the per-thread tap walks and the per-row flush all read it from LDS instead of chasing global loads
+  __shared__ int geo_h[kMaxMaps], geo_w[kMaxMaps], geo_s[kMaxMaps];
+  __shared__ int cm_slot[kMaxMaps + 1], cm_map[kMaxMaps];  // LDS-resident maps in slot order: first slot, map id
+  __shared__ int used_s, ncoarse_s;
   const int tid = threadIdx.x;
   const int pair = blockIdx.x * kTapBlock + tid;
   const int nmaps = cams * L;
+  const bool lds_geo = nmaps <= kMaxMaps;
   const int b0 = (blockIdx.x * kTapBlock) / PA;  // sample of the block's first pair
 
+  if (lds_geo && tid < nmaps) {
+    geo_h[tid] = ss[2 * tid];
+    geo_w[tid] = ss[2 * tid + 1];
+    geo_s[tid] = start[tid];
+  }
+  if (tid < kMaxMaps) map_base[tid] = -1;
+  __syncthreads();
   if (tid == 0) {
-    int used = 0;
-    for (int m = 0; m < kMaxMaps; ++m) map_base[m] = -1;
-    if (nmaps <= kMaxMaps) {
+    int used = 0, nc = 0;
+    if (lds_geo) {
       for (int s = L - 1; s >= 0; --s) {
         int need = 0;
-        for (int c = 0; c < cams; ++c) need += ss[2 * (c * L + s)] * ss[2 * (c * L + s) + 1];
+        for (int c = 0; c < cams; ++c) need += geo_h[c * L + s] * geo_w[c * L + s];
         if (used + need > kLdsRows) break;
         for (int c = 0; c < cams; ++c) {
           map_base[c * L + s] = used;
-          used += ss[2 * (c * L + s)] * ss[2 * (c * L + s) + 1];
+          cm_slot[nc] = used;
+          cm_map[nc++] = c * L + s;
+          used += geo_h[c * L + s] * geo_w[c * L + s];
         }
       }
     }
+    cm_slot[nc] = used;
     used_s = used;
+    ncoarse_s = nc;
   }
   __syncthreads();
   const int used = used_s;
@@ -95,10 +112,10 @@ __global__ __launch_bounds__(kTapBlock) void daf_tap_pass_kernel(
   if (kept) {
     for (int s = 0; s < L; ++s) {
       const int cs = cam * L + s;
-      const int H = ss[2 * cs], W = ss[2 * cs + 1];
+      const int H = lds_geo ? geo_h[cs] : ss[2 * cs], W = lds_geo ? geo_w[cs] : ss[2 * cs + 1];
       const Taps t = make_taps(l.y, l.x, H, W);
-      const int lbase = (nmaps <= kMaxMaps && b == b0) ? map_base[cs] : -1;
-      const int gbase = b * num_feat + start[cs];
+      const int lbase = (lds_geo && b == b0) ? map_base[cs] : -1;
+      const int gbase = b * num_feat + (lds_geo ? geo_s[cs] : start[cs]);
       const int id0 = (pair * L + s) << 2;
 #pragma unroll
       for (int corner = 0; corner < 4; ++corner) {
@@ -119,31 +136,28 @@ __global__ __launch_bounds__(kTapBlock) void daf_tap_pass_kernel(
     }
   }
   __syncthreads();
-  // ---- phase 2: one global atomic per touched coarse row
-  if (nmaps <= kMaxMaps) {
-    for (int m = 0; m < nmaps; ++m) {
-      const int mb = map_base[m];
-      if (mb < 0) continue;
-      const int size = ss[2 * m] * ss[2 * m + 1];
-      const int grow = b0 * num_feat + start[m];
-      for (int i = tid; i < size; i += kTapBlock) {
-        const int c = tab[mb + i];
-        if (c > 0) {
-          const int base = atomicAdd(counter + grow + i, c);
-          if (PLACE) tab[mb + i] = base;
-        }
+  // ---- phase 2: one global atomic per touched coarse row, all LDS slots in one sweep
+  {
+    const int nc = ncoarse_s;
+    for (int i = tid; i < used; i += kTapBlock) {
+      const int c = tab[i];
+      if (c > 0) {
+        int k = 0;
+        while (k + 1 < nc && cm_slot[k + 1] <= i) ++k;
+        const int base = atomicAdd(counter + b0 * num_feat + geo_s[cm_map[k]] + (i - cm_slot[k]), c);
+        if (PLACE) tab[i] = base;
       }
     }
   }
   if (!PLACE) return;
   __syncthreads();
   // ---- phase 3: draw slots from the LDS cursors
-  if (kept && b == b0 && nmaps <= kMaxMaps) {
+  if (kept && b == b0 && lds_geo) {
     for (int s = 0; s < L; ++s) {
       const int cs = cam * L + s;
       const int lbase = map_base[cs];
       if (lbase < 0) continue;
-      const int H = ss[2 * cs], W = ss[2 * cs + 1];
+      const int H = geo_h[cs], W = geo_w[cs];
       const Taps t = make_taps(l.y, l.x, H, W);
       const int id0 = (pair * L + s) << 2;
 #pragma unroll
@@ -274,19 +288,38 @@ __global__ __launch_bounds__(256) void daf_bwd_feat_kernel(
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 old = make_float4(0.f, 0.f, 0.f, 0.f);
     if (cur >= 0 && cur_excl) old = gfeat4[(size_t)cur * 64 + lane];
-    for (int t = 0; t < n; ++t) {
-      const int rt = rl_i(row, t);
-      const int at = rl_i(anchor, t);
-      const float4 g4 = gout4[(size_t)at * 64 + lane];
-      const float wc = wc_s[wv][t][g];
-      if (rt != cur) {
-        flush(cur, cur_excl, old, acc);
-        cur = rt;
-        cur_excl = rl_i(excl, t);
-        acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (cur >= 0 && cur_excl) old = gfeat4[(size_t)cur * 64 + lane];
+    // kAhead grad_out rows in flight: with one load per iteration behind the row-change branch every tap paid a full
+    // memory latency (64 of them per batch)
+    constexpr int kAhead = 8;
+    for (int tb = 0; tb < n; tb += kAhead) {
+      float4 gq[kAhead], oq[kAhead];
+      float wq8[kAhead];
+#pragma unroll
+      for (int k = 0; k < kAhead; ++k) {
+        const int tt = min(tb + k, n - 1);
+        gq[k] = gout4[(size_t)rl_i(anchor, tt) * 64 + lane];
+        // the row's present value as well: most rows hold one or two taps, and a load issued at the row's first tap
+        // is wanted back at its last -- one exposed memory latency per row.  (Rows are sorted: a row's first tap
+        // is loaded before anything of this batch is stored to it.)
+        oq[k] = gfeat4[(size_t)max(rl_i(row, tt), 0) * 64 + lane];
+        wq8[k] = wc_s[wv][tt][g];
       }
-      acc.x += wc * g4.x; acc.y += wc * g4.y; acc.z += wc * g4.z; acc.w += wc * g4.w;
+#pragma unroll
+      for (int k = 0; k < kAhead; ++k) {
+        const int t = tb + k;
+        if (t < n) {
+          const int rt = rl_i(row, t);
+          if (rt != cur) {
+            flush(cur, cur_excl, old, acc);
+            cur = rt;
+            cur_excl = rl_i(excl, t);
+            acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            old = oq[k];
+          }
+          const float wc = wq8[k];
+          acc.x += wc * gq[k].x; acc.y += wc * gq[k].y; acc.z += wc * gq[k].z; acc.w += wc * gq[k].w;
+        }
+      }
     }
     flush(cur, cur_excl, old, acc);
     __builtin_amdgcn_wave_barrier();  // wc_s[wv] is rewritten by the next batch
