@@ -136,16 +136,36 @@ __global__ __launch_bounds__(kTapBlock) void daf_tap_pass_kernel(
     }
   }
   __syncthreads();
-  // ---- phase 2: one global atomic per touched coarse row, all LDS slots in one sweep
+  // ---- phase 2: one global atomic per touched LDS row.  Four slots per thread and trip, so that (place pass) four
+  // atomics are in flight before the first returned base is needed; the map a slot belongs to is found by a cursor
+  // that only moves forward (a thread's slots ascend), i.e. ~nmaps LDS reads per thread in total.
   {
-    const int nc = ncoarse_s;
-    for (int i = tid; i < used; i += kTapBlock) {
-      const int c = tab[i];
-      if (c > 0) {
-        int k = 0;
-        while (k + 1 < nc && cm_slot[k + 1] <= i) ++k;
-        const int base = atomicAdd(counter + b0 * num_feat + geo_s[cm_map[k]] + (i - cm_slot[k]), c);
-        if (PLACE) tab[i] = base;
+    int k = 0;
+    for (int i0 = tid; i0 < used; i0 += 4 * kTapBlock) {
+      int c[4], addr[4], base[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * kTapBlock;
+        c[u] = i < used ? tab[i] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * kTapBlock;
+        addr[u] = 0;
+        if (c[u] > 0) {
+          while (cm_slot[k + 1] <= i) ++k;  // i < used == cm_slot[ncoarse]: stops inside the table
+          addr[u] = b0 * num_feat + geo_s[cm_map[k]] + (i - cm_slot[k]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        base[u] = 0;
+        if (c[u] > 0) base[u] = atomicAdd(counter + addr[u], c[u]);
+      }
+      if (PLACE) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (c[u] > 0) tab[i0 + u * kTapBlock] = base[u];
       }
     }
   }
