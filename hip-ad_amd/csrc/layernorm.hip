@@ -88,36 +88,58 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(float *__restrict__ 
     const int c = 4 * lane + 256 * j;
     g[j] = (gamma && c < N) ? reinterpret_cast<const float4 *>(gamma)[lane + 64 * j] : make_float4(1.f, 1.f, 1.f, 1.f);
   }
-  for (int row = r0; row < r1; ++row) {
-    const float4 *x4 = reinterpret_cast<const float4 *>(x + (size_t)row * N);
-    const float4 *d4 = reinterpret_cast<const float4 *>(dy + (size_t)row * N);
-    const float mu = mean[row], rs = rstd[row];
-    float4 xh[J], gh[J];
-    float s1 = 0.f, s2 = 0.f;
+  // RB rows at a time with all their loads issued first: a wave owns a few rows to keep the parameter-gradient
+  // atomics few, and walking them one by one cost one full memory latency per row
+  constexpr int RB = J == 1 ? 4 : (J == 2 ? 2 : 1);
+  for (int row = r0; row < r1; row += RB) {
+    float4 xv[RB][J], dv[RB][J];
+    float mu[RB], rs[RB];
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
-      const int c = 4 * lane + 256 * j;
-      if (c < N) {
-        const float4 xv = x4[lane + 64 * j], dv = d4[lane + 64 * j];
-        xh[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-        gh[j] = make_float4(dv.x * g[j].x, dv.y * g[j].y, dv.z * g[j].z, dv.w * g[j].w);
-        s1 += gh[j].x + gh[j].y + gh[j].z + gh[j].w;
-        s2 += gh[j].x * xh[j].x + gh[j].y * xh[j].y + gh[j].z * xh[j].z + gh[j].w * xh[j].w;
-        ag[j].x += dv.x * xh[j].x; ag[j].y += dv.y * xh[j].y; ag[j].z += dv.z * xh[j].z; ag[j].w += dv.w * xh[j].w;
-        ab[j].x += dv.x; ab[j].y += dv.y; ab[j].z += dv.z; ab[j].w += dv.w;
-      } else {
-        xh[j] = gh[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = 0; b < RB; ++b) {
+      const int rr = min(row + b, r1 - 1);  // past the wave's last row: a repeat, computed but neither stored nor summed
+      const float4 *x4 = reinterpret_cast<const float4 *>(x + (size_t)rr * N);
+      const float4 *d4 = reinterpret_cast<const float4 *>(dy + (size_t)rr * N);
+      mu[b] = mean[rr];
+      rs[b] = rstd[rr];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const bool in = 4 * lane + 256 * j < N;
+        xv[b][j] = in ? x4[lane + 64 * j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        dv[b][j] = in ? d4[lane + 64 * j] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
-    const float m1 = wave_sum64(s1) / (float)N, m2 = wave_sum64(s2) / (float)N;
-    if (dx) {
-      float4 *o4 = reinterpret_cast<float4 *>(dx + (size_t)row * N);
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+      const bool live = row + b < r1;
+      float4 xh[J], gh[J];
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int j = 0; j < J; ++j) {
         const int c = 4 * lane + 256 * j;
-        if (c < N)
-          o4[lane + 64 * j] = make_float4(rs * (gh[j].x - m1 - xh[j].x * m2), rs * (gh[j].y - m1 - xh[j].y * m2),
-                                          rs * (gh[j].z - m1 - xh[j].z * m2), rs * (gh[j].w - m1 - xh[j].w * m2));
+        if (c < N) {
+          const float4 xq = xv[b][j], dq = dv[b][j];
+          xh[j] = make_float4((xq.x - mu[b]) * rs[b], (xq.y - mu[b]) * rs[b], (xq.z - mu[b]) * rs[b], (xq.w - mu[b]) * rs[b]);
+          gh[j] = make_float4(dq.x * g[j].x, dq.y * g[j].y, dq.z * g[j].z, dq.w * g[j].w);
+          s1 += gh[j].x + gh[j].y + gh[j].z + gh[j].w;
+          s2 += gh[j].x * xh[j].x + gh[j].y * xh[j].y + gh[j].z * xh[j].z + gh[j].w * xh[j].w;
+          if (live) {
+            ag[j].x += dq.x * xh[j].x; ag[j].y += dq.y * xh[j].y; ag[j].z += dq.z * xh[j].z; ag[j].w += dq.w * xh[j].w;
+            ab[j].x += dq.x; ab[j].y += dq.y; ab[j].z += dq.z; ab[j].w += dq.w;
+          }
+        } else {
+          xh[j] = gh[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+      const float m1 = wave_sum64(s1) / (float)N, m2 = wave_sum64(s2) / (float)N;
+      if (dx && live) {
+        float4 *o4 = reinterpret_cast<float4 *>(dx + (size_t)(row + b) * N);
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          const int c = 4 * lane + 256 * j;
+          if (c < N)
+            o4[lane + 64 * j] = make_float4(rs[b] * (gh[j].x - m1 - xh[j].x * m2), rs[b] * (gh[j].y - m1 - xh[j].y * m2),
+                                            rs[b] * (gh[j].z - m1 - xh[j].z * m2), rs[b] * (gh[j].w - m1 - xh[j].w * m2));
+        }
       }
     }
   }
