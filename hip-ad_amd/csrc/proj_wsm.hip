@@ -134,20 +134,25 @@ __global__ __launch_bounds__(T) void weights_softmax_fwd_kernel(
   const int n = L * P * G;
   const float *ua = u + ba * (ucs ? (long)cams * n : (long)n);
   const float *vb = v ? v + b * cams * n : nullptr;
-  // pass 1 (j-order): online max / sum over this thread's (cam, j) entries
+  // pass 1 (j-order, cameras flattened: entry e = cam*n + j keeps e % G == tid % G because G | n): online max / sum
+  // over this thread's entries, four loads in flight per trip (one load per trip left the kernel waiting a memory
+  // latency per element: 31 us for 9 MB of weights)
   float m = -INFINITY, s = 0.f;
-  for (int cam = 0; cam < cams; ++cam) {
-    const float *vc = vb ? vb + (long)cam * n : nullptr;
-    const float *uc = ua + (long)cam * ucs;
-    for (int j = tid; j < n; j += T) {
-      const float x = uc[j] + (vc ? vc[j] : 0.f);
-      if (x > m) {
-        s = s * __expf(m - x) + 1.f;
-        m = x;
-      } else {
-        s += __expf(x - m);
+  const int total = cams * n;
+  for (int e0 = tid; e0 < total; e0 += 4 * T) {
+    float xs[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = e0 + q * T;
+      xs[q] = -INFINITY;
+      if (e < total) {
+        const int cam = e / n, j = e - cam * n;
+        xs[q] = ua[(long)cam * ucs + j] + (vb ? vb[e] : 0.f);
       }
     }
+    const float mn = fmaxf(fmaxf(m, xs[0]), fmaxf(fmaxf(xs[1], xs[2]), xs[3]));  // xs[0] is always a real entry
+    s = s * __expf(m - mn) + ((__expf(xs[0] - mn) + __expf(xs[1] - mn)) + (__expf(xs[2] - mn) + __expf(xs[3] - mn)));
+    m = mn;
   }
   red_m[tid] = m;
   red_s[tid] = s;
@@ -171,16 +176,25 @@ __global__ __launch_bounds__(T) void weights_softmax_fwd_kernel(
   // pass 2 (o-order): consecutive threads write consecutive weights; u / v are gathered (32-byte runs, L1/L2)
   float *wa = w + ba * (long)cams * n;
   const int LG = L * G, CLG = cams * LG;
-  for (int o = tid; o < cams * n; o += T) {
-    const int p = o / CLG;
-    const int r = o - p * CLG;
-    const int cam = r / LG;
-    const int lg = r - cam * LG;           // l*G + g
-    const int l = lg / G;
-    const int j = (l * P + p) * G + g;
-    float val = __expf(ua[(long)cam * ucs + j] + (vb ? vb[(long)cam * n + j] : 0.f) - gm) * inv;
-    if (keep) val *= keep[(ba * cams + cam) * P + p];
-    wa[o] = val;
+  for (int o0 = tid; o0 < total; o0 += 4 * T) {
+    float lg4[4], kp4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int o = min(o0 + q * T, total - 1);  // past the end: a repeat of the last element, not stored
+      const int p = o / CLG;
+      const int r = o - p * CLG;
+      const int cam = r / LG;
+      const int lg = r - cam * LG;           // l*G + g
+      const int l = lg / G;
+      const int j = (l * P + p) * G + g;
+      lg4[q] = ua[(long)cam * ucs + j] + (vb ? vb[(long)cam * n + j] : 0.f);
+      kp4[q] = keep ? keep[(ba * cams + cam) * P + p] : 1.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int o = o0 + q * T;
+      if (o < total) wa[o] = __expf(lg4[q] - gm) * inv * kp4[q];
+    }
   }
 }
 
@@ -206,16 +220,27 @@ __global__ __launch_bounds__(T) void weights_softmax_bwd_kernel(
   const int LG = L * G, CLG = cams * LG;
   // dot[g] = sum over the softmax set of (d w) * softmax   (o-order: coalesced reads of grad_w)
   float dot = 0.f;
-  for (int o = tid; o < cams * n; o += T) {
-    const int p = o / CLG;
-    const int r = o - p * CLG;
-    const int cam = r / LG;
-    const int lg = r - cam * LG;
-    const int l = lg / G;
-    const int j = (l * P + p) * G + g;
-    float gy = gwa[o];
-    if (keep) gy *= keep[(ba * cams + cam) * P + p];
-    dot += gy * __expf(ua[(long)cam * ucs + j] + (vb ? vb[(long)cam * n + j] : 0.f) - gm) * inv;
+  const int total = cams * n;
+  for (int o0 = tid; o0 < total; o0 += 4 * T) {
+    float gy4[4], lg4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int o = o0 + q * T;
+      gy4[q] = 0.f;
+      lg4[q] = gm;
+      if (o < total) {
+        const int p = o / CLG;
+        const int r = o - p * CLG;
+        const int cam = r / LG;
+        const int lg = r - cam * LG;
+        const int l = lg / G;
+        const int j = (l * P + p) * G + g;
+        gy4[q] = gwa[o] * (keep ? keep[(ba * cams + cam) * P + p] : 1.f);
+        lg4[q] = ua[(long)cam * ucs + j] + (vb ? vb[(long)cam * n + j] : 0.f);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dot += gy4[q] * __expf(lg4[q] - gm) * inv;
   }
   red[tid] = dot;
   __syncthreads();
@@ -231,13 +256,23 @@ __global__ __launch_bounds__(T) void weights_softmax_bwd_kernel(
     const int lp = j / G;
     const int l = lp / P, p = lp - l * P;
     float acc = 0.f;
-    for (int cam = 0; cam < cams; ++cam) {
-      float gy = gwa[(((long)p * cams + cam) * L + l) * G + g];
-      if (keep) gy *= keep[(ba * cams + cam) * P + p];
-      const float sm = __expf(ua[(long)cam * ucs + j] + (vb ? vb[(long)cam * n + j] : 0.f) - gm) * inv;
-      const float gx = sm * (gy - gdot);
-      if (ucs) gua[(long)cam * ucs + j] = gx; else acc += gx;
-      if (gxa) gxa[(long)cam * n + j] = gx;
+    for (int cam0 = 0; cam0 < cams; cam0 += 3) {
+      float gy3[3], lg3[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int cam = min(cam0 + q, cams - 1);
+        gy3[q] = gwa[(((long)p * cams + cam) * L + l) * G + g] * (keep ? keep[(ba * cams + cam) * P + p] : 1.f);
+        lg3[q] = ua[(long)cam * ucs + j] + (vb ? vb[(long)cam * n + j] : 0.f);
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int cam = cam0 + q;
+        if (cam < cams) {
+          const float gx = __expf(lg3[q] - gm) * inv * (gy3[q] - gdot);
+          if (ucs) gua[(long)cam * ucs + j] = gx; else acc += gx;
+          if (gxa) gxa[(long)cam * n + j] = gx;
+        }
+      }
     }
     if (!ucs) gua[j] = acc;
   }
