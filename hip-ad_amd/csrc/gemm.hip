@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 #include "hipad.h"
+#include "wave_ops.h"
 #include "daf_common.h"
 
 namespace hipad {
@@ -186,9 +187,7 @@ __device__ __forceinline__ void gemm_tile(short (*TA)[LDS_STRIDE], short (*TB)[L
 #pragma unroll
         for (int e = 0; e < 8; ++e) s8 += (float)__builtin_bit_cast(__bf16, (short)t[e]);
       }
-      s8 += __shfl_xor(s8, 1);
-      s8 += __shfl_xor(s8, 2);
-      rsum += s8;
+      rsum += quad_sum(s8);
     }
     __syncthreads();
   }
@@ -363,7 +362,7 @@ __global__ __launch_bounds__(256) void linear_relu_ln_fwd_kernel(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float t = ps[i][r];
-        t += __shfl_xor(t, 8); t += __shfl_xor(t, 4); t += __shfl_xor(t, 2); t += __shfl_xor(t, 1);
+        t = row_sum(t);  // the 16 lanes l15 = 0..15 of one DPP row (wave_ops.h)
         if (l15 == 0) red[wv][16 * i + 4 * quad + r] = t;
       }
     __syncthreads();
