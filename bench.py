@@ -279,10 +279,13 @@ def _daf_grid_threads(A, P, cams=6, bs=1):
     return ((n_anchor * nchunks + 3) // 4) * 256
 
 
+PMC_FILE = "r01k_daf_pmc_traffic.json"
+
+
 def pmc_traffic(kernel, A, P):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE,
     tools/pmc_traffic.py; MI355X_MICROARCH.md HBM section), or None when the file has no such launch."""
-    path = os.path.join(ROOT, "profiles", "r01f_daf_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", PMC_FILE)
     if not os.path.exists(path):
         return None
     with open(path) as f:
@@ -298,11 +301,11 @@ def roofline_of(daf):
     dcall = next(d for d in daf.calls if d["name"] == dom[0])
     alg = daf.alg_bytes(dcall, dom[1])
     achieved = alg / (kt[dom] * 1e-3) / 1e9
-    kname = {"fwd": "daf_fwd_c256_kernel<4>", "bwd_lw": "daf_bwd_lw_kernel<4, true>"}[dom[1]]
+    kname = {"fwd": "daf_fwd_c256_kernel<4, true>", "bwd_lw": "daf_bwd_lw_kernel<4, true, true>"}[dom[1]]
     return dict(bound="hbm", kernel=f"{kname} [{dom[0]}: A={dcall['A']} P={dcall['P']}]",
                 achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                 traffic=pmc_traffic(kname, dcall["A"], dcall["P"]),
-                traffic_source="profiles/r01f_daf_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                traffic_source="profiles/" + PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                "`bench.py --workload daf_stage2`, bytes per launch)",
                 alg_bytes_per_launch=alg, avg_launch_ms=round(kt[dom], 4),
                 all_kernels_ms={f"{k[0]}_{k[1]}": round(v, 4) for k, v in kt.items()})
