@@ -111,7 +111,7 @@ def test_decoder_two_frames_match_reference(golden, mode):
     # LayerNorm moves it between 0.09 and 0.23 -- one instance whose temporal top-k neighbour changed), so that case is
     # bounded by the 99th percentile of the element errors plus a loose cap on the worst one
     TOL_FRAME1_DEEP = TOL_DEEP if mode == "torch_fp32" else 0.35
-    TOL_FRAME1_DEEP_Q99 = 0.06
+    TOL_FRAME1_DEEP_Q99 = 0.08   # = the frame-0 bound on the worst element
 
     def npy(t):
         return t.detach().float().cpu().numpy()
