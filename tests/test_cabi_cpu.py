@@ -103,3 +103,24 @@ def test_product_path_never_imports_oracle():
                     if re.search(r"^\s*(from|import)\s+oracle\b|oracle/_build|libhipad_oracle", txt, flags=re.M):
                         bad.append(os.path.join(dirpath, f))
     assert not bad, f"product files reference the oracle: {bad}"
+
+
+def test_library_path_override(tmp_path):
+    """HIPAD_LIB selects another build of the same ABI; a path without a library fails loudly."""
+    import shutil
+    import subprocess
+    import sys
+    from hipad_amd import lib
+    other = tmp_path / "libhipad_copy.so"
+    shutil.copy(lib.SO_PATH, other)
+    code = ("import hipad_amd; from hipad_amd import lib; lib.load(); "
+            "print(lib.SO_PATH); print(lib.load().hipad_abi_version())")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, HIPAD_LIB=str(other)),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[0] == str(other)
+    missing = subprocess.run([sys.executable, "-c", code], cwd=root,
+                             env=dict(os.environ, HIPAD_LIB=str(tmp_path / "nope.so")),
+                             capture_output=True, text=True, timeout=300)
+    assert missing.returncode != 0 and "HipadError" in missing.stderr
