@@ -311,9 +311,30 @@ def roofline_of(daf):
                 all_kernels_ms={f"{k[0]}_{k[1]}": round(v, 4) for k, v in kt.items()})
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves as a CHILD
+    `python -m torch.distributed.run` (before this process has touched the GPU; never an exec), relay its
+    output (rank 0's JSON line) and exit with its code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(a))
     rank, world, local = dist_setup(a.gpus)
+    if world != a.gpus:
+        raise SystemExit(f"bench: --gpus {a.gpus} but the launcher started {world} rank(s); refusing to report "
+                         f"a {world}-rank number as the {a.gpus}-GPU point")
     dev = torch.device("cuda", local)
     full = a.workload == "stage2_full"
     infer = a.workload == "stage2_infer"

@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void linear_assignment_kernel(int *__restrict_
     for (int j = tid; j <= C; j += 256) { minv[j] = kInf; used[j] = 0; }
     if (tid == 0) { p[0] = i; j0_s = 0; }
     __syncthreads();
+    bool infeasible = false;
     while (true) {
       const int j0 = j0_s;
       const int i0 = p[j0];
@@ -79,6 +80,13 @@ __global__ __launch_bounds__(256) void linear_assignment_kernel(int *__restrict_
 #pragma unroll
       for (int w = 1; w < 4; ++w)
         if (red_val[w] < delta || (red_val[w] == delta && red_idx[w] < j1)) { delta = red_val[w]; j1 = red_idx[w]; }
+      if (j1 == 0x7fffffff || !(delta < kInf)) {
+        // no unvisited column with a finite reduced cost (+inf / NaN costs): the problem is infeasible for this row.
+        // SciPy raises; a kernel cannot -- the row stays unassigned (-1) and the search for it ends here, without
+        // indexing p[] / way[] by the sentinel.  (Uniform: every thread derived j1 / delta from the same LDS words.)
+        infeasible = true;
+        break;
+      }
       // shift potentials (used[] now includes j0: thread 0 wrote it before the barrier above)
       for (int j = tid; j <= C; j += 256) {
         if (used[j]) { u[p[j]] += delta; v[j] -= delta; }
@@ -89,6 +97,10 @@ __global__ __launch_bounds__(256) void linear_assignment_kernel(int *__restrict_
       const bool done = p[j1] == 0;
       __syncthreads();
       if (done) break;
+    }
+    if (infeasible) {
+      __syncthreads();
+      continue;
     }
     if (tid == 0) {  // flip the alternating path
       int j0 = j0_s;

@@ -54,7 +54,27 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(float *__restrict__ pa
 
 struct AdamCoef {
   float lr0, lr1, beta1, beta2, eps, wd, max_norm;
+  hipad_lr_schedule sched;
 };
+
+// Learning-rate factor of iteration `it` (0-based count of steps already taken), mmcv 1.7.1 LrUpdaterHook with
+// by_epoch=False as the reference configures it (projects/configs/hipad_b2d_stage2.py:643-649 lr_config):
+//   regular(it) = CosineAnnealing: target + 0.5 (1 - target) (1 + cos(pi it / max_iters)), target = min_lr_ratio
+//   warm-up (it < warmup_iters, linear): regular(it) * (1 - (1 - it / warmup_iters) (1 - warmup_ratio))
+// policy 0 = constant.  The same closed form is hipad_amd.optim.lr_factor (tests compare the two).
+__device__ __host__ __forceinline__ float lr_factor(const hipad_lr_schedule &s, int it) {
+  if (s.policy == 0) return 1.f;
+  float f = 1.f;
+  if (s.policy == 1 && s.max_iters > 0) {
+    const float x = fminf((float)it / (float)s.max_iters, 1.f);
+    f = s.min_lr_ratio + 0.5f * (1.f - s.min_lr_ratio) * (1.f + cosf(3.14159265358979323846f * x));
+  }
+  if (s.warmup_iters > 0 && it < s.warmup_iters) {
+    const float k = (1.f - (float)it / (float)s.warmup_iters) * (1.f - s.warmup_ratio);
+    f *= 1.f - k;
+  }
+  return f;
+}
 
 __device__ __forceinline__ void adam_elem(float &p, float &g, float &m, float &v, float lr, float c, float b1, float b2,
                                           float eps, float wd, float inv_bc1, float inv_sqrt_bc2) {
@@ -69,7 +89,8 @@ __device__ __forceinline__ void adam_elem(float &p, float &g, float &m, float &v
 __global__ __launch_bounds__(256) void adamw_flat_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
                                                          float *__restrict__ v, long n, long n_group0,
                                                          const float *__restrict__ partial, int *__restrict__ step,
-                                                         float *__restrict__ norm_out, AdamCoef k, int zero_grad) {
+                                                         float *__restrict__ norm_out, unsigned short *__restrict__ shadow,
+                                                         AdamCoef k, int zero_grad) {
   __shared__ float sh[4];
   float s = 0.f;
   for (int i = threadIdx.x; i < kNormBlocks; i += 256) s += partial[i];
@@ -78,6 +99,9 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float *__restrict__ p, 
   float c = 1.f;
   if (k.max_norm > 0.f) c = fminf(1.f, k.max_norm / (norm + 1e-6f));
   const int t = *step + 1;  // every block reads the same (old) value; block 0 publishes the new one last
+  const float lrf = lr_factor(k.sched, t - 1);
+  k.lr0 *= lrf;
+  k.lr1 *= lrf;
   const float inv_bc1 = 1.f / (1.f - powf(k.beta1, (float)t));
   const float inv_sqrt_bc2 = 1.f / sqrtf(1.f - powf(k.beta2, (float)t));
   const long n4 = n >> 2;
@@ -94,6 +118,13 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float *__restrict__ p, 
     adam_elem(P.z, G.z, Mv.z, V.z, l2, c, k.beta1, k.beta2, k.eps, k.wd, inv_bc1, inv_sqrt_bc2);
     adam_elem(P.w, G.w, Mv.w, V.w, l3, c, k.beta1, k.beta2, k.eps, k.wd, inv_bc1, inv_sqrt_bc2);
     p4[i] = P; m4[i] = Mv; v4[i] = V;
+    if (shadow) {  // bf16 copy of the updated parameters (operand format of the MFMA kernels), same element order
+      const __bf16 b0 = (__bf16)P.x, b1 = (__bf16)P.y, b2 = (__bf16)P.z, b3 = (__bf16)P.w;
+      ushort4 sv;
+      sv.x = __builtin_bit_cast(unsigned short, b0); sv.y = __builtin_bit_cast(unsigned short, b1);
+      sv.z = __builtin_bit_cast(unsigned short, b2); sv.w = __builtin_bit_cast(unsigned short, b3);
+      reinterpret_cast<ushort4 *>(shadow)[i] = sv;
+    }
     if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (blockIdx.x == 0) {
@@ -101,12 +132,23 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float *__restrict__ p, 
       float P = p[i], G = g[i], Mv = m[i], V = v[i];
       adam_elem(P, G, Mv, V, i < n_group0 ? k.lr0 : k.lr1, c, k.beta1, k.beta2, k.eps, k.wd, inv_bc1, inv_sqrt_bc2);
       p[i] = P; m[i] = Mv; v[i] = V;
+      if (shadow) shadow[i] = __builtin_bit_cast(unsigned short, (__bf16)P);
       if (zero_grad) g[i] = 0.f;
     }
   }
   // the step counter is bumped by a trailing one-thread kernel (adamw_bump_kernel): blocks of THIS grid may
   // still be reading *step when block 0 gets here
-  if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) *norm_out = norm;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) {
+    norm_out[0] = norm;
+    norm_out[1] = k.lr0;  // the learning rate of group 0 this step actually used
+  }
+}
+
+// bf16 copy of a flat fp32 buffer (initial fill of the shadow; afterwards adamw_flat_kernel maintains it)
+__global__ __launch_bounds__(256) void shadow_bf16_kernel(unsigned short *__restrict__ dst, const float *__restrict__ src, long n) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    dst[i] = __builtin_bit_cast(unsigned short, (__bf16)src[i]);
 }
 
 __global__ void adamw_bump_kernel(int *step) { *step += 1; }
@@ -119,19 +161,32 @@ extern "C" {
 
 size_t hipad_adamw_workspace(void) { return kNormBlocks * sizeof(float); }
 
+float hipad_lr_factor(const hipad_lr_schedule *sched, int iteration) {
+  if (!sched) return 1.f;
+  return lr_factor(*sched, iteration);
+}
+
+int hipad_shadow_bf16(unsigned short *dst, const float *src, long long n, hipad_stream_t stream) {
+  if (!dst || !src || n <= 0) return HIPAD_EINVAL;
+  hipLaunchKernelGGL(shadow_bf16_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, dst, src, (long)n);
+  return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
+}
+
 int hipad_adamw_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, long long n, long long n_group0,
                      float lr0, float lr1, float beta1, float beta2, float eps, float weight_decay, float max_norm,
                      int *step_dev, float *norm_out_dev, void *workspace, size_t workspace_bytes, int zero_grad,
-                     hipad_stream_t stream_) {
+                     const hipad_lr_schedule *sched, unsigned short *shadow_bf16, hipad_stream_t stream_) {
   if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev || n <= 0) return HIPAD_EINVAL;
   if (!workspace || workspace_bytes < hipad_adamw_workspace()) return HIPAD_EWORKSPACE;
   if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0) return HIPAD_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   float *partial = (float *)workspace;
   hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(kNormBlocks), dim3(256), 0, stream, partial, grad, (long)(n >> 2), (long)n);
-  AdamCoef k{lr0, lr1, beta1, beta2, eps, weight_decay, max_norm};
+  if (shadow_bf16 && ((uintptr_t)shadow_bf16 & 7) != 0) return HIPAD_EINVAL;
+  AdamCoef k{lr0, lr1, beta1, beta2, eps, weight_decay, max_norm, {0, 0, 1.f, 0, 1.f}};
+  if (sched) k.sched = *sched;
   hipLaunchKernelGGL(adamw_flat_kernel, dim3(2048), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, (long)n,
-                     (long)n_group0, (const float *)partial, step_dev, norm_out_dev, k, zero_grad);
+                     (long)n_group0, (const float *)partial, step_dev, norm_out_dev, shadow_bf16, k, zero_grad);
   hipLaunchKernelGGL(adamw_bump_kernel, dim3(1), dim3(1), 0, stream, step_dev);
   return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
 }

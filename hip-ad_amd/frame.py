@@ -92,6 +92,9 @@ def surrogate_objective(model_outs, depths=None):
     return torch.stack(terms).sum()
 
 
+BF16_SHADOW = True  # keep a bf16 copy of the parameters current in the optimiser kernel (MFMA operand format)
+
+
 class TrainStep:
     """forward + objective + backward + gradient all-reduce + clip + AdamW step for one frame batch
     (optimiser settings of the reference: AdamW lr 2e-4 wd 1e-3, backbone lr x0.5, grad-clip 25,
@@ -109,8 +112,11 @@ class TrainStep:
         mult = opt["paramwise_cfg"]["custom_keys"]["img_backbone"]["lr_mult"]
         self.max_norm = cfg["optimizer_config"]["grad_clip"]["max_norm"]
         # parameters, gradients and AdamW moments in flat buffers; clip + step = two launches
+        # lr_config (linear warm-up + cosine annealing per iteration) is evaluated inside the optimiser kernel
+        runner = cfg.get("runner") or {}
         self.opt = FlatAdamW([(rest, opt["lr"]), (bb, opt["lr"] * mult)], weight_decay=opt["weight_decay"],
-                             max_norm=self.max_norm, comm_dtype=comm_dtype)
+                             max_norm=self.max_norm, comm_dtype=comm_dtype, lr_config=cfg.get("lr_config"),
+                             max_iters=int(runner.get("max_iters", 0)), bf16_shadow=BF16_SHADOW)
         self.params = self.opt.params
         self.grads = self.opt.grads
         self._loosened = False
@@ -163,8 +169,7 @@ class GraphedTrainStep:
         import torch.distributed as dist
         from . import runtime_env
         if not runtime_env.graph_replay_is_safe():
-            raise RuntimeError("captured training steps need %s in the environment before the HIP runtime starts "
-                               "(import hipad_amd before torch); see hipad_amd/runtime_env.py" % runtime_env.REQUIRED)
+            raise RuntimeError("captured training steps refused: %s (see hipad_amd/runtime_env.py)" % runtime_env.why_unsafe())
         self.model, self.frames = model, frames
         self.inner = TrainStep(model, cfg, comm_dtype=comm_dtype, capturable=True)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
@@ -284,7 +289,7 @@ class GraphedInference:
     def __init__(self, model, frames, warm_frames=3):
         from . import runtime_env
         if not runtime_env.graph_replay_is_safe():
-            raise RuntimeError("captured steps need %s in the environment before the HIP runtime starts" % runtime_env.REQUIRED)
+            raise RuntimeError("captured steps refused: %s (see hipad_amd/runtime_env.py)" % runtime_env.why_unsafe())
         self.model, self.frames = model.eval(), frames
         self.dec = model.head.onedecoder_head
         dev, bs = frames.device, frames.bs

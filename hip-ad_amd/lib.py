@@ -42,7 +42,9 @@ SIGNATURES = {
     "hipad_focal_loss_forward": (c_int, [c_void_p] * 6 + [ctypes.c_longlong, c_int, c_int, ctypes.c_float, ctypes.c_float, c_void_p]),
     "hipad_adamw_workspace": (c_size_t, []),
     "hipad_adamw_step": (c_int, [c_void_p] * 4 + [ctypes.c_longlong] * 2 + [ctypes.c_float] * 7
-                         + [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+                         + [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p]),
+    "hipad_lr_factor": (ctypes.c_float, [c_void_p, c_int]),
+    "hipad_shadow_bf16": (c_int, [c_void_p, c_void_p, ctypes.c_longlong, c_void_p]),
     "hipad_attention_forward": (c_int, [c_void_p] * 5 + [c_int] * 5 + [ctypes.c_float, ctypes.c_float, ctypes.c_uint,
                                                                      c_void_p, c_void_p]),
     "hipad_attention_backward": (c_int, [c_void_p] * 10 + [c_int] * 5 + [ctypes.c_float, ctypes.c_float,
@@ -323,8 +325,30 @@ def linear_backward(dy2, y_relu, x2, weight, dx, dw, db):
     check(st, "hipad_linear_backward")
 
 
+class LrScheduleStruct(ctypes.Structure):
+    """hipad_lr_schedule of include/hipad.h."""
+    _fields_ = [("policy", c_int), ("warmup_iters", c_int), ("warmup_ratio", ctypes.c_float), ("max_iters", c_int),
+                ("min_lr_ratio", ctypes.c_float)]
+
+
+def lr_factor(sched, iteration):
+    """Host evaluation of the kernel's learning-rate factor (hipad_lr_factor); ``sched``: LrScheduleStruct or None."""
+    return float(load().hipad_lr_factor(None if sched is None else ctypes.byref(sched), int(iteration)))
+
+
+def shadow_bf16(dst, src):
+    """dst (bf16, n) <- src (fp32, n), element order unchanged."""
+    lib = load()
+    _req(src, torch.float32, "src")
+    _req(dst, torch.bfloat16, "dst")
+    if dst.numel() != src.numel():
+        raise HipadError("shadow_bf16: lengths differ")
+    with torch.cuda.device(src.device):
+        check(lib.hipad_shadow_bf16(dst.data_ptr(), src.data_ptr(), src.numel(), stream_ptr(src.device)), "hipad_shadow_bf16")
+
+
 def adamw_step(param, grad, exp_avg, exp_avg_sq, n_group0, lr0, lr1, betas, eps, weight_decay, max_norm, step_dev,
-               norm_out, workspace, zero_grad=True):
+               norm_out, workspace, zero_grad=True, sched=None, shadow=None):
     """Clip (global norm) + AdamW over flat fp32 buffers; see include/hipad.h."""
     lib = load()
     for t, nm in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
@@ -334,12 +358,19 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, n_group0, lr0, lr1, betas, eps,
         raise HipadError("adamw_step: buffers differ in length")
     if step_dev.dtype != torch.int32 or not step_dev.is_cuda:
         raise HipadError("adamw_step: step_dev must be a device int32 tensor")
+    if norm_out is not None and (norm_out.numel() < 2 or norm_out.dtype != torch.float32):
+        raise HipadError("adamw_step: norm_out must hold two floats (norm, learning rate)")
+    if shadow is not None:
+        _req(shadow, torch.bfloat16, "shadow")
+        if shadow.numel() != n:
+            raise HipadError("adamw_step: shadow buffer differs in length")
     with torch.cuda.device(param.device):
         st = lib.hipad_adamw_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), n,
                                   int(n_group0), float(lr0), float(lr1), float(betas[0]), float(betas[1]), float(eps),
                                   float(weight_decay), float(max_norm if max_norm else 0.0), step_dev.data_ptr(),
                                   _ptr(norm_out), workspace.data_ptr(), workspace.numel() * workspace.element_size(),
-                                  int(bool(zero_grad)), stream_ptr(param.device))
+                                  int(bool(zero_grad)), None if sched is None else ctypes.addressof(sched),
+                                  _ptr(shadow), stream_ptr(param.device))
     check(st, "hipad_adamw_step")
 
 

@@ -4,10 +4,54 @@ launches (hip-ad_amd/csrc/optim.hip) instead of torch's ~170 multi-tensor launch
 Reference: AdamW lr 2e-4, weight_decay 1e-3, ``paramwise_cfg`` lr_mult 0.5 for ``img_backbone``,
 ``grad_clip`` max_norm 25 (projects/configs/hipad_b2d_stage2.py:629-641).
 """
+import math
+
 import torch
 
 from . import lib as _lib
 from .dist import FlatGrads, flat_offsets
+
+
+def lr_factor(lr_config, iteration, max_iters):
+    """Closed form of the reference's learning-rate schedule at 0-based ``iteration`` (factor on the base lr).
+
+    ``lr_config`` as in projects/configs/hipad_b2d_stage2.py:643-649: policy "CosineAnnealing", warmup "linear",
+    warmup_iters 500, warmup_ratio 1/3, min_lr_ratio 1e-3, driven per iteration (IterBasedRunner).  Restates mmcv
+    1.7.1 ``CosineAnnealingLrUpdaterHook.get_lr`` + ``LrUpdaterHook.get_warmup_lr`` (mmcv is not installed here, so
+    this restatement is not pinned against mmcv itself); the device evaluates the same expression inside
+    adamw_flat_kernel (optim.hip ``lr_factor``)."""
+    if not lr_config:
+        return 1.0
+    policy = lr_config.get("policy")
+    f = 1.0
+    if policy == "CosineAnnealing":
+        target = lr_config.get("min_lr_ratio", 0.0)
+        x = min(iteration / max_iters, 1.0) if max_iters > 0 else 0.0
+        f = target + 0.5 * (1.0 - target) * (1.0 + math.cos(math.pi * x))
+    elif policy not in (None, "fixed", "Fixed"):
+        raise NotImplementedError(f"lr policy {policy!r} (the HiP-AD configs use CosineAnnealing)")
+    warm = lr_config.get("warmup")
+    wi = lr_config.get("warmup_iters", 0)
+    if warm is not None and iteration < wi:
+        if warm != "linear":
+            raise NotImplementedError(f"warmup {warm!r} (the HiP-AD configs use linear)")
+        k = (1.0 - iteration / wi) * (1.0 - lr_config.get("warmup_ratio", 0.1))
+        f *= 1.0 - k
+    return f
+
+
+def schedule_struct(lr_config, max_iters):
+    """``lr_config`` dict -> the C struct hipad_adamw_step takes (None for a constant rate)."""
+    if not lr_config:
+        return None
+    lr_factor(lr_config, 0, max_iters)  # validates policy / warmup names
+    s = _lib.LrScheduleStruct()
+    s.policy = 1 if lr_config.get("policy") == "CosineAnnealing" else 0
+    s.warmup_iters = int(lr_config.get("warmup_iters", 0)) if lr_config.get("warmup") else 0
+    s.warmup_ratio = float(lr_config.get("warmup_ratio", 0.1))
+    s.max_iters = int(max_iters)
+    s.min_lr_ratio = float(lr_config.get("min_lr_ratio", 0.0))
+    return s
 
 
 class FlatAdamW:
@@ -16,7 +60,8 @@ class FlatAdamW:
     the moments are flat buffers too.  ``step()`` clips by the global norm and applies AdamW; the pre-clip
     norm is left in ``self.grad_norm`` (device scalar).  State lives on the device: capturable."""
 
-    def __init__(self, groups, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_norm=None, comm_dtype=None):
+    def __init__(self, groups, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_norm=None, comm_dtype=None,
+                 lr_config=None, max_iters=0, bf16_shadow=False):
         if not 1 <= len(groups) <= 2:
             raise ValueError("one or two learning-rate groups")
         plists = [[p for p in ps if p.requires_grad] for ps, _ in groups]
@@ -38,10 +83,41 @@ class FlatAdamW:
         self.exp_avg = torch.zeros_like(self.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
         self.step_count = torch.zeros(1, dtype=torch.int32, device=ref.device)
-        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=ref.device)
+        self._stats = torch.zeros(2, dtype=torch.float32, device=ref.device)  # [pre-clip norm, lr of group 0]
+        self.grad_norm = self._stats[0:1]
+        self.last_lr = self._stats[1:2]
         self._ws = torch.empty(_lib.load().hipad_adamw_workspace(), dtype=torch.uint8, device=ref.device)
+        # learning-rate schedule: evaluated inside the kernel from the device step counter (capturable: a replayed
+        # graph follows warm-up + cosine annealing without recapture or host updates)
+        self.lr_config, self.max_iters = lr_config, max_iters
+        self._sched = schedule_struct(lr_config, max_iters)
+        # bf16 copy of the flat parameter buffer, kept current by the AdamW kernel (operands of the MFMA kernels)
+        self.shadow = None
+        if bf16_shadow:
+            self.shadow = torch.empty(total, dtype=torch.bfloat16, device=ref.device)
+            self.refresh_shadow()
+        self.offsets = offsets
+
+    def refresh_shadow(self):
+        """Re-derive the bf16 shadow from the fp32 parameters (after loading a checkpoint / writing p.data)."""
+        if self.shadow is not None:
+            _lib.shadow_bf16(self.shadow, self.flat_p)
+
+    def shadow_of(self, p):
+        """bf16 view of parameter ``p`` inside the shadow buffer (None when no shadow is kept)."""
+        if self.shadow is None:
+            return None
+        off = (p.data_ptr() - self.flat_p.data_ptr()) // 4
+        if not (0 <= off < self.flat_p.numel()):
+            return None
+        return self.shadow[off:off + p.numel()].view(p.shape)
+
+    def lr_at(self, iteration):
+        """(lr group 0, lr group 1) the kernel uses at 0-based ``iteration`` (host closed form)."""
+        f = lr_factor(self.lr_config, iteration, self.max_iters)
+        return self.lrs[0] * f, self.lrs[1] * f
 
     def step(self, zero_grad=True):
         _lib.adamw_step(self.flat_p, self.grads.flat, self.exp_avg, self.exp_avg_sq, self.n_group0, self.lrs[0],
                         self.lrs[1], self.betas, self.eps, self.weight_decay, self.max_norm, self.step_count,
-                        self.grad_norm, self._ws, zero_grad=zero_grad)
+                        self._stats, self._ws, zero_grad=zero_grad, sched=self._sched, shadow=self.shadow)

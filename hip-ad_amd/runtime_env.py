@@ -29,5 +29,23 @@ def apply():
 
 
 def graph_replay_is_safe():
-    """True when the process environment has the settings captured training steps need."""
-    return all(os.environ.get(k) == v for k, v in REQUIRED.items())
+    """True when the HIP runtime of this process is known to have started with the settings captured steps need:
+    the variables hold the required values AND either the process was started with them (hipad_amd.FLAGS_PRESET) or
+    ``hipad_amd`` was imported before torch (so they were set before the runtime could read them).  A caller that
+    imported torch first and only then hipad_amd has the right values in os.environ but possibly not in the runtime:
+    refused (the replays would return the garbage gradients described above)."""
+    if not all(os.environ.get(k) == v for k, v in REQUIRED.items()):
+        return False
+    import hipad_amd
+    return bool(hipad_amd.FLAGS_PRESET or not hipad_amd.TORCH_IMPORTED_FIRST)
+
+
+def why_unsafe():
+    import hipad_amd
+    bad = {k: os.environ.get(k) for k, v in REQUIRED.items() if os.environ.get(k) != v}
+    if bad:
+        return "environment has %r, needs %r" % (bad, REQUIRED)
+    if hipad_amd.TORCH_IMPORTED_FIRST and not hipad_amd.FLAGS_PRESET:
+        return ("torch was imported before hipad_amd, so the HIP runtime may have started without %r; import hipad_amd "
+                "first or export the variable before starting the process" % (REQUIRED,))
+    return ""

@@ -301,17 +301,33 @@ int hipad_focal_loss_forward(float *loss_per_layer, float *grad_logits, const fl
  *           (projects/configs/hipad_b2d_stage2.py:629-641).
  *   param / grad / exp_avg / exp_avg_sq: n floats each, 16-byte aligned; elements [0, n_group0) step
  *   with lr0, the rest with lr1.  max_norm <= 0 disables clipping.  step_dev: device int32 holding the
- *   number of steps taken so far (incremented here).  norm_out_dev (may be NULL): receives the total
- *   gradient norm BEFORE clipping.  zero_grad != 0 clears grad after it has been consumed.
- *   workspace: hipad_adamw_workspace() bytes of device scratch.
+ *   number of steps taken so far (incremented here).  norm_out_dev (may be NULL): TWO floats, [0] receives the
+ *   total gradient norm BEFORE clipping, [1] the learning rate group 0 used.  zero_grad != 0 clears grad after
+ *   it has been consumed.  workspace: hipad_adamw_workspace() bytes of device scratch.
+ *   sched (may be NULL = constant): the reference's lr_config (mmcv LrUpdaterHook, by_epoch=False;
+ *   projects/configs/hipad_b2d_stage2.py:643-649: CosineAnnealing, linear warm-up 500 iterations from 1/3,
+ *   min_lr_ratio 1e-3).  The factor is evaluated IN the kernel from *step_dev, so a hipGraph-replayed step follows
+ *   the schedule without any host update; hipad_lr_factor() is the same closed form on the host.
+ *   shadow_bf16 (may be NULL): n bf16 values, 8-byte aligned; receives the updated parameters rounded to bf16
+ *   (the operand format of the MFMA kernels, element order unchanged); hipad_shadow_bf16 fills it initially.
  * Arithmetic is torch.nn.utils.clip_grad_norm_ followed by torch.optim.AdamW (decoupled weight decay,
  * bias-corrected moments), fp32.
  * ---------------------------------------------------------------------------------- */
+typedef struct hipad_lr_schedule {
+  int policy;          /* 0 constant, 1 CosineAnnealing */
+  int warmup_iters;    /* 0 = no warm-up; linear warm-up otherwise */
+  float warmup_ratio;
+  int max_iters;
+  float min_lr_ratio;
+} hipad_lr_schedule;
 size_t hipad_adamw_workspace(void);
+float hipad_lr_factor(const hipad_lr_schedule *sched, int iteration);
+int hipad_shadow_bf16(unsigned short *dst, const float *src, long long n, hipad_stream_t stream);
 int hipad_adamw_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, long long n,
                      long long n_group0, float lr0, float lr1, float beta1, float beta2, float eps,
                      float weight_decay, float max_norm, int *step_dev, float *norm_out_dev,
-                     void *workspace, size_t workspace_bytes, int zero_grad, hipad_stream_t stream);
+                     void *workspace, size_t workspace_bytes, int zero_grad, const hipad_lr_schedule *sched,
+                     unsigned short *shadow_bf16, hipad_stream_t stream);
 
 /* Tuning knob (host side, process-wide): target number of (point, camera) pairs one
  * wavefront owns in the forward / backward kernels.  <=0 restores the default. */

@@ -23,6 +23,23 @@ __all__ = ["ResNet", "FPN"]
 _DEPTH = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
 
 
+def load_checkpoint(module, path, strict=False, prefix=None):
+    """state_dict loader restricted to ``torch.load(..., weights_only=True)`` (nothing from the file is executed).
+    Accepts a bare state_dict or mmcv's ``{"state_dict": ...}`` wrapper; ``prefix`` strips e.g. "img_backbone.".
+    Raises FileNotFoundError when the file is absent -- there is no silent fall back to random weights."""
+    import os
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"checkpoint {path!r} requested by the config does not exist (set it to None for a "
+                                "random-init run)")
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    if isinstance(sd, dict) and "state_dict" in sd:
+        sd = sd["state_dict"]
+    if prefix:
+        sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    missing, unexpected = module.load_state_dict(sd, strict=strict)
+    return missing, unexpected
+
+
 class Bottleneck(nn.Module):
     expansion = 4
 
@@ -54,13 +71,15 @@ class Bottleneck(nn.Module):
 
 class ResNet(BaseModule):
     def __init__(self, depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=-1, norm_eval=False,
-                 style="pytorch", with_cp=False, norm_cfg=None, pretrained=None, init_cfg=None, **kwargs):
+                 style="pytorch", with_cp=False, norm_cfg=None, pretrained=None, init_cfg=None,
+                 zero_init_residual=True, **kwargs):
         super().__init__(init_cfg)
         if depth not in _DEPTH or style != "pytorch":
             raise NotImplementedError(f"ResNet depth={depth} style={style}")
         self.depth, self.out_indices = depth, tuple(out_indices)
         self.frozen_stages, self.norm_eval, self.with_cp = frozen_stages, norm_eval, with_cp
         self.pretrained = pretrained
+        self.zero_init_residual = zero_init_residual
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
@@ -94,12 +113,23 @@ class ResNet(BaseModule):
                 p.requires_grad = False
 
     def init_weights(self):
+        """mmdet's ResNet initialisation: Kaiming-normal convolutions, unit BatchNorm, and (``zero_init_residual``,
+        mmdet's default) the last BatchNorm of every bottleneck at zero; or the ``pretrained`` checkpoint.  A
+        checkpoint path that is set but cannot be honoured raises -- a run must not silently start from random
+        weights when the config asks for ImageNet ones (the files are loaded with ``weights_only=True``)."""
+        if self.pretrained:
+            load_checkpoint(self, self.pretrained, strict=False)
+            return
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
             elif isinstance(m, nn.BatchNorm2d):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
+        if self.zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, Bottleneck):
+                    nn.init.constant_(m.bn3.weight, 0)
 
     def forward(self, x):
         x = self.maxpool(self.relu(self.bn1(self.conv1(x))))

@@ -44,8 +44,8 @@ def _tables(level_hw, num_cams, device):
         ss_d, start_d = ss.to(device), start.to(device)
         # host mirrors + int32 twins ride along so later calls need no device->host sync / cast
         ss_d._hipad_host = ss.tolist()
-        ss_d._hipad_i32 = ss_d.int()
-        start_d._hipad_i32 = start_d.int()
+        ss_d._hipad_i32 = ((ss_d.data_ptr(), ss_d._version), ss_d.int())        # see deformable_aggregation._as_i32
+        start_d._hipad_i32 = ((start_d.data_ptr(), start_d._version), start_d.int())
         hit = (ss_d, start_d)
         _tables.cache[key] = hit
     return hit

@@ -42,14 +42,17 @@ def _cross_check(feat, ss, st, loc, w, grad_output):
 def _as_i32(t):
     if t.dtype == torch.int32 and t.is_contiguous():
         return t
+    # int32 twin cached on the tensor object, keyed on (storage address, version counter): a caller that rewrites
+    # spatial_shape / scale_start_index in place gets a fresh copy instead of stale row addresses
+    key = (t.data_ptr(), t._version)
     cached = getattr(t, "_hipad_i32", None)
-    if cached is None or cached.device != t.device:
-        cached = t.contiguous().int()
+    if cached is None or cached[0] != key or cached[1].device != t.device:
+        cached = (key, t.contiguous().int())
         try:
             t._hipad_i32 = cached
         except Exception:
             pass
-    return cached
+    return cached[1]
 
 
 def _as_f32(t):

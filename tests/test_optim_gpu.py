@@ -49,3 +49,32 @@ def test_flat_adamw_rejects_bad_input():
     with pytest.raises(lib.HipadError):
         lib.adamw_step(opt.flat_p, opt.grads.flat[:-4], opt.exp_avg, opt.exp_avg_sq, 0, 1e-3, 1e-3, (0.9, 0.999), 1e-8, 0.0,
                        None, opt.step_count, None, opt._ws)
+
+
+def test_flat_adamw_follows_the_lr_schedule_and_keeps_a_bf16_shadow():
+    """Warm-up + cosine annealing evaluated inside the kernel from the device step counter == torch AdamW driven by
+    the closed form (hipad_amd.optim.lr_factor) through LambdaLR; the bf16 shadow equals the rounded parameters."""
+    from hipad_amd.optim import FlatAdamW, lr_factor
+    lr_config = dict(policy="CosineAnnealing", warmup="linear", warmup_iters=4, warmup_ratio=1.0 / 3, min_lr_ratio=1e-3)
+    max_iters = 9
+    mine, ref = make_params(2), make_params(2)
+    opt = FlatAdamW([(mine[:4], 2e-3), (mine[4:], 1e-3)], weight_decay=1e-2, max_norm=5.0, lr_config=lr_config,
+                    max_iters=max_iters, bf16_shadow=True)
+    for p in mine:
+        assert torch.equal(opt.shadow_of(p), p.detach().to(torch.bfloat16))
+    topt = torch.optim.AdamW([dict(params=ref[:4], lr=2e-3), dict(params=ref[4:], lr=1e-3)], lr=2e-3, weight_decay=1e-2)
+    sched = torch.optim.lr_scheduler.LambdaLR(topt, lambda it: lr_factor(lr_config, it, max_iters))
+    g = torch.Generator().manual_seed(3)
+    for step in range(max_iters):
+        grads = [torch.randn(p.shape, generator=g).cuda() for p in ref]
+        for p, q, gr in zip(mine, ref, grads):
+            p.grad.copy_(gr)
+            q.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_(ref, 5.0)
+        topt.step()
+        sched.step()
+        opt.step()
+        assert abs(float(opt.last_lr) - opt.lr_at(step)[0]) <= 1e-6 * opt.lr_at(step)[0], step
+        for p, q in zip(mine, ref):
+            assert float((p - q).abs().max()) <= 3e-6 * max(1.0, float(q.abs().max())), step
+            assert torch.equal(opt.shadow_of(p), p.detach().to(torch.bfloat16)), step
