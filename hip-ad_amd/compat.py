@@ -163,7 +163,21 @@ class MLPStack(nn.Sequential):
     """nn.Sequential (same children, same state_dict keys) that can run every [Linear(+ReLU), FusedReLU, LayerNorm]
     triple as ONE forward launch (hipad_linear_relu_ln_forward) -- opt-in, see functional.FUSE_LINEAR_LN."""
 
-    def forward(self, x):
+    def forward(self, x, x1=None, residual=None):
+        """``x1`` (same shape as x) is added to the input, ``residual`` (shape of the output) to the result -- both inside
+        the chain kernel on the GPU path (they replace the separate add kernels around the stack)."""
+        from . import chain as CH
+        from . import functional as HF
+        if CH.usable(x):
+            spec = CH.spec_of(self)
+            if spec is not None:
+                return CH.run([CH.Call(spec, x, x1, residual)])[0]
+        if x1 is not None:
+            x = x + x1
+        y = self._forward_layers(x)
+        return y if residual is None else y + residual
+
+    def _forward_layers(self, x):
         from . import functional as HF
         mods = list(self)
         i = 0

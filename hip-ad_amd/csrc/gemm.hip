@@ -429,6 +429,41 @@ __global__ __launch_bounds__(256) void linear_relu_ln_fwd_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Weight / bias gradients of every layer of a group of MLP chains (chain.hip) in ONE grid: entry e computes
+// dW_e[n][k] += sum_m dY_e[m][n] X_e[m][k] and db_e[n] += sum_m dY_e[m][n] with the transposed-operand tile loaders
+// above (one 64 x 32 tile of dW and one 256-row slab of the reduction per workgroup, fp32 atomics into the
+// caller's gradient buffers).  dY is already gated by the chain's reverse sweep.
+// ------------------------------------------------------------------------------------------------------------
+struct ChainDwEntry {
+  const float *dy, *x;
+  float *dw, *db;
+  int M, N, K, ldx;
+  int wg0, tiles_x, tiles_xy, vec;
+};
+struct ChainDwArgs {
+  int n, pad;
+  ChainDwEntry e[HIPAD_CHAIN_MAX_DW];
+};
+
+__global__ __launch_bounds__(256) void chain_dw_kernel(const ChainDwArgs a) {
+  __shared__ short TA[BM][LDS_STRIDE];
+  __shared__ short TB[BN][LDS_STRIDE];
+  const int b = blockIdx.x;
+  int ei = 0;
+  for (int i = 1; i < a.n; ++i)
+    if (b >= a.e[i].wg0) ei = i;
+  const ChainDwEntry &e = a.e[ei];
+  const int t = b - e.wg0;
+  const int bz = t / e.tiles_xy, r = t - bz * e.tiles_xy;
+  if (e.vec)
+    gemm_tile<true, true, 1, true, true>(TA, TB, e.dw, e.dy, nullptr, e.x, nullptr, e.db, e.N, e.K, e.M, e.N, e.ldx, e.K, 0,
+                                         KC, r % e.tiles_x, r / e.tiles_x, bz);
+  else
+    gemm_tile<true, true, 1, false, false>(TA, TB, e.dw, e.dy, nullptr, e.x, nullptr, e.db, e.N, e.K, e.M, e.N, e.ldx, e.K, 0,
+                                           KC, r % e.tiles_x, r / e.tiles_x, bz);
+}
+
 static inline int vec_ok(const void *p, int ld) { return (((uintptr_t)p & 15) == 0 && (ld & 3) == 0) ? 1 : 0; }
 
 // launch gemm_kernel<AT, BT, EPI, va, vb> with the two vector-load flags resolved at run time
@@ -483,6 +518,35 @@ int hipad_linear_relu_ln_forward(float *y, float *x_relu, float *mean, float *rs
                                            x_relu, mean, rstd, x, weight, bias, gamma, beta, M, N, K, eps)
   if (N <= 64) HIPAD_LRL(1); else if (N <= 128) HIPAD_LRL(2); else HIPAD_LRL(4);
 #undef HIPAD_LRL
+  return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
+}
+
+int hipad_chain_backward_dw(const hipad_chain_dw *entries, int nentries, hipad_stream_t stream_) {
+  if (!entries || nentries <= 0) return HIPAD_EINVAL;
+  hipStream_t stream = (hipStream_t)stream_;
+  for (int base = 0; base < nentries; base += HIPAD_CHAIN_MAX_DW) {
+    const int n = nentries - base < HIPAD_CHAIN_MAX_DW ? nentries - base : HIPAD_CHAIN_MAX_DW;
+    ChainDwArgs a;
+    a.n = n;
+    a.pad = 0;
+    long long wgs = 0;
+    for (int i = 0; i < n; ++i) {
+      const hipad_chain_dw &s = entries[base + i];
+      int rc = check_lin(s.M, s.N, s.K);
+      if (rc != HIPAD_OK) return rc;
+      if (!s.dy || !s.x || !s.dw || s.ldx < s.K) return HIPAD_EINVAL;
+      ChainDwEntry &e = a.e[i];
+      e.dy = s.dy; e.x = s.x; e.dw = s.dw; e.db = s.db;
+      e.M = s.M; e.N = s.N; e.K = s.K; e.ldx = s.ldx;
+      e.tiles_x = (s.K + BN - 1) / BN;
+      e.tiles_xy = e.tiles_x * ((s.N + BM - 1) / BM);
+      e.vec = vec_ok(s.dy, s.N) & vec_ok(s.x, s.ldx);
+      e.wg0 = (int)wgs;
+      wgs += (long long)e.tiles_xy * ((s.M + KC - 1) / KC);
+      if (wgs >= (1ll << 30)) return HIPAD_ERANGE;
+    }
+    hipLaunchKernelGGL(chain_dw_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a);
+  }
   return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
 }
 

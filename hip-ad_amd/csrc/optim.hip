@@ -153,6 +153,43 @@ __global__ __launch_bounds__(256) void shadow_bf16_kernel(unsigned short *__rest
 
 __global__ void adamw_bump_kernel(int *step) { *step += 1; }
 
+// bf16 (and transposed bf16) copies of many fp32 matrices, one 32 x 32 tile per workgroup of 256 threads
+__global__ __launch_bounds__(256) void pack_weights_kernel(unsigned short *const *__restrict__ dst,
+                                                           unsigned short *const *__restrict__ dst_t,
+                                                           const float *const *__restrict__ src, const int *__restrict__ rows,
+                                                           const int *__restrict__ cols, const int *__restrict__ tile_start,
+                                                           int n_mats) {
+  __shared__ unsigned short T[32][33];
+  const int b = blockIdx.x;
+  int lo = 0, hi = n_mats - 1;  // last matrix whose first tile is <= b
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tile_start[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  const int m = lo, R = rows[m], C = cols[m];
+  const int tc = (C + 31) >> 5, t = b - tile_start[m];
+  const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+  const float *s = src[m];
+  unsigned short *d = dst ? dst[m] : nullptr, *dt = dst_t[m];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    unsigned short v = 0;
+    if (r < R && c < C) {
+      v = __builtin_bit_cast(unsigned short, (__bf16)s[(size_t)r * C + c]);
+      if (d) d[(size_t)r * C + c] = v;
+    }
+    T[ty + 8 * i][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (r < R && c < C) dt[(size_t)c * R + r] = T[tx][ty + 8 * i];
+  }
+}
+
 }  // namespace hipad
 
 using namespace hipad;
@@ -164,6 +201,14 @@ size_t hipad_adamw_workspace(void) { return kNormBlocks * sizeof(float); }
 float hipad_lr_factor(const hipad_lr_schedule *sched, int iteration) {
   if (!sched) return 1.f;
   return lr_factor(*sched, iteration);
+}
+
+int hipad_pack_weights(unsigned short *const *dst, unsigned short *const *dst_t, const float *const *src, const int *rows,
+                       const int *cols, const int *tile_start, int n_mats, int total_tiles, hipad_stream_t stream) {
+  if (!dst_t || !src || !rows || !cols || !tile_start || n_mats <= 0 || total_tiles <= 0) return HIPAD_EINVAL;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, dst, dst_t, src, rows, cols,
+                     tile_start, n_mats);
+  return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
 }
 
 int hipad_shadow_bf16(unsigned short *dst, const float *src, long long n, hipad_stream_t stream) {

@@ -123,6 +123,8 @@ def attention(q, k, v, heads, scale=None, p_drop=0.0, seed=0):
 import os as _os
 
 LINEAR_MODE = _os.environ.get("HIPAD_LINEAR_MODE", "mfma_bf16")  # "torch_fp32": library fp32 GEMMs (fp32 parity runs)
+# whole MLP stacks (Linear / ReLU / LayerNorm sequences) as one forward + two backward launches (hipad_amd.chain)
+USE_CHAINS = _os.environ.get("HIPAD_USE_CHAINS", "1") == "1"
 LINEAR_INPLACE_GRAD = _os.environ.get("HIPAD_LINEAR_INPLACE_GRAD", "1") == "1"
 LINEAR_BWD = _os.environ.get("HIPAD_LINEAR_BWD", "mfma")  # "torch": debugging aid, backward by library matmuls
 # ids of the parameters whose gradient some kernel here has accumulated IN PLACE into ``param.grad`` (Linear /

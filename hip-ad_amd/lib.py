@@ -44,6 +44,10 @@ SIGNATURES = {
     "hipad_adamw_step": (c_int, [c_void_p] * 4 + [ctypes.c_longlong] * 2 + [ctypes.c_float] * 7
                          + [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p]),
     "hipad_lr_factor": (ctypes.c_float, [c_void_p, c_int]),
+    "hipad_chain_forward": (c_int, [c_void_p, c_int, c_void_p]),
+    "hipad_chain_backward_dx": (c_int, [c_void_p, c_int, c_void_p]),
+    "hipad_chain_backward_dw": (c_int, [c_void_p, c_int, c_void_p]),
+    "hipad_pack_weights": (c_int, [c_void_p] * 6 + [c_int, c_int, c_void_p]),
     "hipad_shadow_bf16": (c_int, [c_void_p, c_void_p, ctypes.c_longlong, c_void_p]),
     "hipad_attention_forward": (c_int, [c_void_p] * 5 + [c_int] * 5 + [ctypes.c_float, ctypes.c_float, ctypes.c_uint,
                                                                      c_void_p, c_void_p]),

@@ -329,6 +329,77 @@ int hipad_adamw_step(float *param, float *grad, float *exp_avg, float *exp_avg_s
                      void *workspace, size_t workspace_bytes, int zero_grad, const hipad_lr_schedule *sched,
                      unsigned short *shadow_bf16, hipad_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * MLP chains (hip-ad_amd/csrc/chain.hip; weight gradients: chain_dw_kernel in gemm.hip).
+ * Replaces: the reference's linear_relu_ln stacks and heads -- ([Linear, ReLU] x in_loops, LayerNorm) x
+ *           out_loops, Linear (+ mmcv Scale) (+ residual) -- models/blocks.py:32-42 used by the refinement
+ *           heads (det/blocks.py:77-156, map/blocks.py:80-135, plan/blocks.py:16-157, motion/blocks.py:16-50,
+ *           ego/blocks.py:14-75), the anchor encoders (det/blocks.py:22-74, map/blocks.py:18-42) and the small
+ *           camera / command / target-point encoders: one launch per direction for a whole GROUP of chains
+ *           instead of one per Linear / LayerNorm.
+ * A chain: x = x0[r * ldx0 + c] (+ x1[r * ldx1 + c]); for every layer l: h = x W_l^T + b_l, ReLU if flags & 1,
+ *   then x = LayerNorm(h) * gamma + beta if flags & 2 else x = h; out[r * ldo + c] = x * out_scale[c] +
+ *   residual[r * ldr + c] for the last layer.  1 <= K, N <= 256; layer l + 1 has K = N of layer l.
+ *   w: bf16 [N][K] row-major (16-byte aligned when K % 8 == 0); bias / gamma / beta fp32 or NULL.
+ * Training: `save` (fp32 scratch owned by the caller) receives, at the given float offsets, h (M x N: post-ReLU,
+ *   pre-LayerNorm activation), y (M x N: LayerNorm output, only for flags & 2) and stats (M x 2: mean, rstd);
+ *   xsum (M x K0, may be NULL) receives x0 + x1 when x1 is given.  With save == NULL nothing is kept (inference).
+ * hipad_chain_backward_dx: reverse sweep.  dout (M rows, ldo) is the gradient of `out`; for every layer the gated
+ *   gradient of its pre-activation is written to dy + off_dy (M x N) for hipad_chain_backward_dw, gamma / beta /
+ *   out_scale gradients are ADDED atomically into dgamma / dbeta / dscale, and the input gradient is written to
+ *   dx (M rows, lddx; NULL skips it).  wt: bf16 [K][N] (the transposed weights).
+ * hipad_chain_backward_dw: for every entry dw[N][K] += dy^T x, db[N] += column sums of dy (atomics; x: M rows, ldx).
+ * ---------------------------------------------------------------------------------- */
+#define HIPAD_CHAIN_MAX_LAYERS 6
+#define HIPAD_CHAIN_MAX_CHAINS 8
+#define HIPAD_CHAIN_MAX_DW 48
+#define HIPAD_CHAIN_NONE 0xffffffffu
+typedef struct hipad_chain_layer {
+  const unsigned short *w;
+  const float *bias, *gamma, *beta;
+  unsigned off_h, off_y, off_stats;
+  int K, N, flags;
+  float eps;
+} hipad_chain_layer;
+typedef struct hipad_chain {
+  const float *x0, *x1;
+  float *xsum, *out;
+  const float *out_scale, *residual;
+  float *save;
+  int ldx0, ldx1, ldo, ldr, M, nlayers;
+  hipad_chain_layer layers[HIPAD_CHAIN_MAX_LAYERS];
+} hipad_chain;
+typedef struct hipad_chain_grad_layer {
+  const unsigned short *wt;
+  const float *gamma;
+  float *dgamma, *dbeta;
+  unsigned off_h, off_stats, off_dy;
+  int K, N, flags;
+  float eps;
+} hipad_chain_grad_layer;
+typedef struct hipad_chain_grad {
+  const float *dout, *out_scale;
+  float *dscale, *dx;
+  const float *save;
+  float *dy;
+  int ldo, lddx, M, nlayers;
+  hipad_chain_grad_layer layers[HIPAD_CHAIN_MAX_LAYERS];
+} hipad_chain_grad;
+typedef struct hipad_chain_dw {
+  const float *dy, *x;
+  float *dw, *db;
+  int M, N, K, ldx;
+} hipad_chain_dw;
+int hipad_chain_forward(const hipad_chain *chains, int nchains, hipad_stream_t stream);
+int hipad_chain_backward_dx(const hipad_chain_grad *chains, int nchains, hipad_stream_t stream);
+int hipad_chain_backward_dw(const hipad_chain_dw *entries, int nentries, hipad_stream_t stream);
+/* bf16 copies of a batch of fp32 matrices in one launch: dst_t[i][k][n] = bf16(src[i][n][k]) (transposed) and, where
+ * dst[i] != NULL, dst[i][n][k] = bf16(src[i][n][k]).  All tables live in DEVICE memory: n_mats pointers / dimensions and
+ * tile_start[n_mats + 1] = exclusive prefix sum of ceil(rows / 32) * ceil(cols / 32); total_tiles = its last entry. */
+int hipad_pack_weights(unsigned short *const *dst, unsigned short *const *dst_t, const float *const *src,
+                       const int *rows, const int *cols, const int *tile_start, int n_mats, int total_tiles,
+                       hipad_stream_t stream);
+
 /* Tuning knob (host side, process-wide): target number of (point, camera) pairs one
  * wavefront owns in the forward / backward kernels.  <=0 restores the default. */
 void hipad_daf_set_pairs_per_wave(int fwd, int bwd);

@@ -50,7 +50,7 @@ def score_head(embed_dims, out_dim=1):
 
 def mlp_head(embed_dims, out_dim):
     """[Linear, ReLU] x 2 then a Linear to ``out_dim`` values (Sequential indices 0..4)."""
-    return Sequential(*linear_relu(embed_dims, embed_dims), *linear_relu(embed_dims, embed_dims), Linear(embed_dims, out_dim))
+    return MLPStack(*linear_relu(embed_dims, embed_dims), *linear_relu(embed_dims, embed_dims), Linear(embed_dims, out_dim))
 
 
 @ATTENTION.register_module()

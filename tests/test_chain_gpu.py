@@ -1,0 +1,202 @@
+"""MLP-chain kernels (hip-ad_amd/csrc/chain.hip + chain_dw_kernel in gemm.hip) against (a) the per-layer HIP kernels
+they replace (same bf16-operand numerics: tight bound) and (b) plain torch fp32 (BASELINE.json's 1e-2 bf16 class;
+gradients compared in the Frobenius norm because a ReLU gate that flips on a pre-activation of 1e-3 moves single
+elements by whole dy*w terms, see tests/test_linear_gpu.py).  Shapes are the decoder's: refinement heads on 900 / 100
+/ 48 / 5400 rows, box-encoder parts on strided 2..3-column slices written into one concatenated tensor, ragged widths
+(11, 10, 2, 1, 40, 24 outputs), one row."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def fro(a, b):
+    return float((a.detach().double() - b.detach().double()).norm() / b.detach().double().norm().clamp_min(1e-12))
+
+
+def build(kind, width=256, in_dims=None, out_dim=None):
+    from hipad_amd.compat import Linear, MLPStack, Scale
+    from projects.mmdet3d_plugin.models.blocks import linear_relu_ln, mlp_head
+    torch.manual_seed(0)
+    if kind == "reg":      # refinement regression head (det/blocks.py:93-99): 5 Linear, 2 LayerNorm, Scale
+        m = MLPStack(*linear_relu_ln(width, 2, 2), Linear(width, out_dim), Scale([1.0] * out_dim))
+        with torch.no_grad():
+            m[-1].scale.copy_(torch.linspace(0.5, 1.5, out_dim))
+    elif kind == "cls":    # score head: [Linear, ReLU, LayerNorm] x 2, Linear
+        m = MLPStack(*linear_relu_ln(width, 1, 2), Linear(width, out_dim))
+    elif kind == "enc":    # anchor-encoder part: [Linear, ReLU, LayerNorm] x 2 from a few input columns
+        m = MLPStack(*linear_relu_ln(width, 1, 2, in_dims))
+    elif kind == "mlp":    # [Linear, ReLU] x 2, Linear
+        m = mlp_head(width, out_dim)
+    else:
+        raise KeyError(kind)
+    for name, p in m.named_parameters():   # LayerNorm / bias parameters away from their trivial init
+        if p.dim() == 1 and not name.endswith("scale"):
+            with torch.no_grad():
+                p.add_(torch.randn_like(p) * 0.1)
+    return m.cuda()
+
+
+def grads_of(mod, params_like=None):
+    return [p.grad.clone() for p in mod.parameters()]
+
+
+def run_three_ways(mod, inputs, gout_seed=1, x1=None, residual=None):
+    """Outputs and gradients of the chain kernel, the per-layer HIP kernels and torch fp32 for one module call."""
+    from hipad_amd import functional as HF
+    res = {}
+    for mode in ("chain", "layers", "torch"):
+        m = copy.deepcopy(mod)
+        for p in m.parameters():
+            p.grad = torch.full_like(p, 0.25)   # gradients accumulate on top of what is there
+        xs = [None if t is None else t.detach().clone().requires_grad_(True) for t in (inputs, x1, residual)]
+        HF.USE_CHAINS = mode == "chain"
+        try:
+            if mode == "torch":
+                with HF.linear_mode("torch_fp32"):
+                    y = m(xs[0], xs[1], xs[2])
+            else:
+                y = m(xs[0], xs[1], xs[2])
+        finally:
+            HF.USE_CHAINS = True
+        g = torch.Generator().manual_seed(gout_seed)
+        go = torch.randn(y.shape, generator=g).cuda()
+        y.backward(go)
+        res[mode] = (y.detach(), [None if t is None else t.grad for t in xs], [p.grad - 0.25 for p in m.parameters()])
+    return res
+
+
+def check(res, tight=2e-3, loose=2e-2):
+    """chain vs the per-layer HIP kernels: tight (same operand rounding, different summation order).  chain vs torch fp32:
+    the output within `loose`; gradients no further from torch than the per-layer kernels are (x1.5 + 1e-2): through five
+    bf16 layers with ReLU gates and LayerNorms the per-layer kernels themselves sit at several per cent (gate flips)."""
+    yc, xc, pc = res["chain"]
+    yl, xl, pl = res["layers"]
+    yt, xt, pt = res["torch"]
+    assert fro(yc, yl) < tight, ("layers", "out", fro(yc, yl))
+    assert fro(yc, yt) < loose, ("torch", "out", fro(yc, yt))
+    for a, b, t in zip(xc, xl, xt):
+        if b is not None:
+            assert fro(a, b) < tight * 3, ("layers", "dx", fro(a, b))
+            assert fro(a, t) < 1.5 * fro(b, t) + 1e-2, ("torch", "dx", fro(a, t), fro(b, t))
+    for i, (a, b, t) in enumerate(zip(pc, pl, pt)):
+        if float(b.abs().max()) > 0:
+            assert fro(a, b) < tight * 3, ("layers", "param", i, tuple(b.shape), fro(a, b))
+            assert fro(a, t) < 1.5 * fro(b, t) + 1e-2, ("torch", "param", i, tuple(b.shape), fro(a, t), fro(b, t))
+
+
+@pytest.mark.parametrize("kind,M,out_dim", [("reg", 900, 11), ("reg", 100, 40), ("reg", 48, 12), ("cls", 900, 10),
+                                             ("cls", 900, 2), ("cls", 144, 1), ("mlp", 5400, 24), ("mlp", 1, 6),
+                                             ("cls", 5400, 1), ("reg", 17, 11)])
+def test_head_chains(kind, M, out_dim):
+    mod = build(kind, 256, out_dim=out_dim)
+    g = torch.Generator().manual_seed(M + out_dim)
+    x = torch.randn(1, M, 256, generator=g).cuda()
+    check(run_three_ways(mod, x))
+
+
+def test_input_sum_and_residual_are_fused():
+    mod = build("reg", 256, out_dim=12)
+    g = torch.Generator().manual_seed(3)
+    x, x1, res = (torch.randn(2, 240, n, generator=g).cuda() for n in (256, 256, 12))
+    out = run_three_ways(mod, x, x1=x1, residual=res)
+    check(out)
+    # both summands receive the same gradient; the residual receives the output gradient
+    assert torch.equal(out["chain"][1][0], out["chain"][1][1])
+    assert fro(out["chain"][1][2], out["torch"][1][2]) < 1e-6
+
+
+@pytest.mark.parametrize("width,in_dims,lo", [(128, 3, 0), (32, 3, 3), (32, 2, 6), (64, 3, 8), (256, 40, 0), (256, 12, 0)])
+def test_encoder_parts_on_strided_column_slices(width, in_dims, lo):
+    mod = build("enc", width, in_dims=in_dims)
+    g = torch.Generator().manual_seed(width + lo)
+    full = torch.randn(1, 900, max(11, in_dims), generator=g).cuda()
+    from hipad_amd import functional as HF
+    res = {}
+    for mode in ("chain", "layers", "torch"):
+        m = copy.deepcopy(mod)
+        for p in m.parameters():
+            p.grad = torch.zeros_like(p)
+        a = full.clone().requires_grad_(True)
+        HF.USE_CHAINS = mode == "chain"
+        try:
+            if mode == "torch":
+                with HF.linear_mode("torch_fp32"):
+                    y = m(a[..., lo:lo + in_dims])
+            else:
+                y = m(a[..., lo:lo + in_dims])
+        finally:
+            HF.USE_CHAINS = True
+        y.backward(torch.ones_like(y) * torch.linspace(-1, 1, width).cuda())
+        res[mode] = (y.detach(), [a.grad], [p.grad for p in m.parameters()])
+    check(res, tight=3e-3, loose=3e-2)
+
+
+def test_group_of_chains_writes_one_concatenated_tensor():
+    """The four parts of the box encoder (det/blocks.py:22-74, mode "cat") as ONE launch into one (M, 256) tensor."""
+    from hipad_amd import chain as CH
+    widths, cols = [128, 32, 32, 64], [(0, 3), (3, 6), (6, 8), (8, 11)]
+    mods = [build("enc", w, in_dims=b - a) for w, (a, b) in zip(widths, cols)]
+    g = torch.Generator().manual_seed(11)
+    anchor = torch.randn(2, 450, 11, generator=g).cuda()
+    go = torch.randn(2, 450, 256, generator=g).cuda()
+    # chain group
+    a1 = anchor.clone().requires_grad_(True)
+    for m in mods:
+        for p in m.parameters():
+            p.grad = torch.zeros_like(p)
+    col = 0
+    calls = []
+    for m, w, (lo, hi) in zip(mods, widths, cols):
+        calls.append(CH.Call(CH.spec_of(m), a1[..., lo:hi], out_slot=(0, col), out_width=256))
+        col += w
+    (out,) = CH.run(calls)
+    assert out.shape == (2, 450, 256)
+    out.backward(go)
+    got = (out.detach(), a1.grad.clone(), [p.grad.clone() for m in mods for p in m.parameters()])
+    # per-layer kernels + torch.cat
+    from hipad_amd import functional as HF
+    ref_mods = [copy.deepcopy(m) for m in mods]
+    for m in ref_mods:
+        for p in m.parameters():
+            p.grad = torch.zeros_like(p)
+    a2 = anchor.clone().requires_grad_(True)
+    HF.USE_CHAINS = False
+    try:
+        ref = torch.cat([m(a2[..., lo:hi]) for m, (lo, hi) in zip(ref_mods, cols)], dim=-1)
+    finally:
+        HF.USE_CHAINS = True
+    ref.backward(go)
+    assert fro(got[0], ref) < 2e-3
+    assert fro(got[1], a2.grad) < 5e-3
+    for a, b in zip(got[2], [p.grad for m in ref_mods for p in m.parameters()]):
+        assert fro(a, b) < 5e-3, tuple(b.shape)
+
+
+def test_more_than_eight_chains_and_no_grad():
+    from hipad_amd import chain as CH
+    mods = [build("cls", 256, out_dim=1) for _ in range(11)]
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(1, 48, 256, generator=g).cuda() for _ in mods]
+    with torch.no_grad():
+        outs = CH.run([CH.Call(CH.spec_of(m), x) for m, x in zip(mods, xs)])
+        from hipad_amd import functional as HF
+        HF.USE_CHAINS = False
+        try:
+            refs = [m(x) for m, x in zip(mods, xs)]
+        finally:
+            HF.USE_CHAINS = True
+    assert len(outs) == 11
+    for a, b in zip(outs, refs):
+        assert fro(a, b) < 2e-3
+
+
+def test_unsupported_stacks_fall_back_to_layers():
+    from hipad_amd import chain as CH
+    from hipad_amd.compat import Linear, MLPStack
+    wide = MLPStack(Linear(256, 512), Linear(512, 256)).cuda()
+    assert CH.spec_of(wide) is None
+    y = wide(torch.randn(4, 256).cuda())
+    assert y.shape == (4, 256)
