@@ -56,12 +56,26 @@ class CDw(ctypes.Structure):
 _shadow_cache = {}
 
 
-def bf16_pair(weight):
-    """(bf16 [N][K], bf16 [K][N]) copies of a 2-D fp32 parameter.
+def pack_fragments(a):
+    """P(A) of include/hipad.h (hipad_pack_weights): the bf16 copy of a 2-D matrix in MFMA-fragment order, zero-padded to
+    16-row x 32-column blocks; block (tr, s), lane = 16 quad + l15 owns A[16 tr + l15][32 s + 8 quad + 0..7]."""
+    r, d = a.shape
+    tr, s = (r + 15) // 16, (d + 31) // 32
+    pad = torch.zeros(tr * 16, s * 32, dtype=torch.float32, device=a.device)
+    pad[:r, :d] = a
+    return pad.view(tr, 16, s, 4, 8).permute(0, 2, 3, 1, 4).contiguous().to(torch.bfloat16).view(-1)
 
-    An optimiser that keeps shadows current (hipad_amd.optim.FlatAdamW: the AdamW kernel writes the row-major copy, a
-    pack kernel the transposed one) attaches them as ``weight._hipad_shadow``; otherwise the pair is derived here and
-    cached on (storage address, version counter), so in-place torch updates are seen."""
+
+def packed_numel(rows, depth):
+    return ((rows + 15) // 16) * ((depth + 31) // 32) * 512
+
+
+def bf16_pair(weight):
+    """(P(W), P(W^T)): the chain kernels' bf16 operand copies of a 2-D fp32 parameter W [N][K].
+
+    An optimiser that keeps them current (hipad_amd.optim.FlatAdamW: one pack launch per step) attaches them as
+    ``weight._hipad_shadow``; otherwise the pair is derived here and cached on (storage address, version counter), so
+    in-place torch updates are seen."""
     pair = getattr(weight, "_hipad_shadow", None)
     if pair is not None:
         return pair
@@ -69,8 +83,8 @@ def bf16_pair(weight):
     hit = _shadow_cache.get(key)
     stamp = (weight.data_ptr(), weight._version, tuple(weight.shape))
     if hit is None or hit[0] != stamp:
-        w = weight.detach()
-        hit = (stamp, w.to(torch.bfloat16).contiguous(), w.t().to(torch.bfloat16).contiguous())
+        w = weight.detach().float()
+        hit = (stamp, pack_fragments(w), pack_fragments(w.t()))
         _shadow_cache[key] = hit
     return hit[1], hit[2]
 

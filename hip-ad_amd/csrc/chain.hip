@@ -60,6 +60,8 @@ struct ChainFwd {                      // 88 + 6 * 56 = 424 bytes
 };
 struct ChainFwdArgs {
   int nchains, pad;
+  unsigned long long *stamps;          // diagnostic build aid (hipad_chain_debug_stamps): cycle stamps of workgroup 0
+  int tile0[HIPAD_CHAIN_MAX_CHAINS];   // first workgroup of every chain (also in c[i].tile0)
   ChainFwd c[HIPAD_CHAIN_MAX_CHAINS];
 };
 
@@ -83,57 +85,85 @@ struct ChainBwd {                      // 72 + 336 = 408 bytes
 };
 struct ChainBwdArgs {
   int nchains, pad;
+  int tile0[HIPAD_CHAIN_MAX_CHAINS];
   ChainBwd c[HIPAD_CHAIN_MAX_CHAINS];
 };
 
-// 8 consecutive bf16 of a weight row as one MFMA B fragment.  VEC: K % 8 == 0 and the base 16-byte aligned, so an
-// in-range start has all 8 in range; otherwise element-wise guarded loads (only the tiny K = 2, 3, 6, 12 input layers).
-template <bool VEC>
-__device__ __forceinline__ bf16x8 ch_ldw(const unsigned short *__restrict__ row, int kk, int K, bool rowok) {
-  bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (VEC) {
-    if (rowok && kk < K) v = *reinterpret_cast<const bf16x8 *>(row + kk);
-  } else {
+// The workgroup's chain descriptor, copied ONCE from the kernel-argument segment into LDS (one vector load per lane).
+// Read in place, the ~60 scalar loads the compiler spreads over the layer loop each paid a trip to the argument buffer
+// (host-visible memory: ~1.5 us per cache line; measured ~7 us per LAYER for a single-workgroup launch).
+template <typename Desc, typename Args>
+__device__ __forceinline__ const Desc &ch_stage_desc(Desc &lds, const Args &a) {
+  int ci = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (rowok && kk + j < K) v[j] = (short)row[kk + j];
-  }
-  return v;
+  for (int i = 1; i < HIPAD_CHAIN_MAX_CHAINS; ++i)
+    if (i < a.nchains && (int)blockIdx.x >= a.tile0[i]) ci = i;
+  const unsigned *src = reinterpret_cast<const unsigned *>(&a.c[ci]);
+  unsigned *dst = reinterpret_cast<unsigned *>(&lds);
+  if (threadIdx.x < sizeof(Desc) / 4) dst[threadIdx.x] = src[threadIdx.x];
+  __syncthreads();
+  return lds;
 }
 
 // All B fragments this wave needs for one layer: tiles wv, wv + 4, ... of 16 output columns, ksteps reduction steps.
-// rows = output columns of the layer (N forward, K backward), depth = reduction length, ld = row length of the matrix.
+// The matrix is in MFMA-fragment order (hipad.h, hipad_pack_weights): block (t, s) = 64 lanes x 16 bytes, so a fragment
+// is ONE fully coalesced 1 KiB wave load with no per-lane condition at all (the padding is stored as zeros).  History:
+// row-major weights read as 16 rows x 64 bytes per instruction took ~190 cycles per load to issue (2.5 us per 256 x 256
+// layer and workgroup); per-lane `if`s or a select behind the loads made the compiler wait for each load in turn
+// (~10 us per layer).  The `t < ntiles` / `s < ksteps` guards are wave-uniform scalar branches.
+template <bool FULL>
 __device__ __forceinline__ void ch_fetch(bf16x8 (&bw)[CH_MAXT][CH_MAXS], const unsigned short *__restrict__ w, int rows,
-                                         int depth, int wv, int l15, int quad) {
+                                         int depth, int wv, int lane) {
+  const bf16x8 *base = reinterpret_cast<const bf16x8 *>(w) + lane;
+  if (FULL) {  // rows = depth = 256: every tile and step exists, straight-line code, 32 loads in flight
+#pragma unroll
+    for (int tt = 0; tt < CH_MAXT; ++tt)
+#pragma unroll
+      for (int s = 0; s < CH_MAXS; ++s) bw[tt][s] = base[((wv + 4 * tt) * CH_MAXS + s) * 64];
+    return;
+  }
   const int ksteps = (depth + 31) >> 5, ntiles = (rows + 15) >> 4;
-  const bool vec = (depth & 7) == 0;
 #pragma unroll
   for (int tt = 0; tt < CH_MAXT; ++tt) {
     const int t = wv + 4 * tt;
     if (t < ntiles) {  // wave-uniform
-      const int n = 16 * t + l15;
-      const bool nok = n < rows;
-      const unsigned short *row = w + (size_t)(nok ? n : 0) * depth;
 #pragma unroll
-      for (int s = 0; s < CH_MAXS; ++s) {
-        if (s < ksteps) {  // uniform
-          const int kk = 32 * s + 8 * quad;
-          bw[tt][s] = vec ? ch_ldw<true>(row, kk, depth, nok) : ch_ldw<false>(row, kk, depth, nok);
-        }
-      }
+      for (int s = 0; s < CH_MAXS; ++s)
+        if (s < ksteps) bw[tt][s] = base[(t * ksteps + s) * 64];  // uniform
     }
   }
 }
 
-// acc[tt][i] += A(LDS operand tile, rows 16 i ..) x B(bw[tt]) for the wave's tiles
-template <int R>
+// four consecutive elements p[c0 .. c0 + 3] of an n-vector (elements past n read as 0), branch-free
+__device__ __forceinline__ float4 ch_ld4(const float *__restrict__ p, int c0, int n) {
+  const float a = p[c0 + 0 < n ? c0 + 0 : 0], b = p[c0 + 1 < n ? c0 + 1 : 0], c = p[c0 + 2 < n ? c0 + 2 : 0],
+              d = p[c0 + 3 < n ? c0 + 3 : 0];
+  return make_float4(c0 + 0 < n ? a : 0.f, c0 + 1 < n ? b : 0.f, c0 + 2 < n ? c : 0.f, c0 + 3 < n ? d : 0.f);
+}
+
+// acc[tt][i] = A(LDS operand tile, rows 16 i ..) x B(bw[tt]) for the wave's tiles
+template <int R, bool FULL>
 __device__ __forceinline__ void ch_mma(f32x4 (&acc)[CH_MAXT][R / 16], const bf16x8 (&bw)[CH_MAXT][CH_MAXS],
                                        const short (*X)[CH_XS], int rows, int depth, int wv, int l15, int quad) {
+#pragma unroll
+  for (int tt = 0; tt < CH_MAXT; ++tt)
+#pragma unroll
+    for (int i = 0; i < R / 16; ++i) acc[tt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (FULL) {  // one A fragment feeds the four independent accumulators of the wave's tiles
+#pragma unroll
+    for (int s = 0; s < CH_MAXS; ++s)
+#pragma unroll
+      for (int i = 0; i < R / 16; ++i) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&X[16 * i + l15][32 * s + 8 * quad]);
+#pragma unroll
+        for (int tt = 0; tt < CH_MAXT; ++tt)
+          acc[tt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bw[tt][s], acc[tt][i], 0, 0, 0);
+      }
+    return;
+  }
   const int ksteps = (depth + 31) >> 5, ntiles = (rows + 15) >> 4;
 #pragma unroll
   for (int tt = 0; tt < CH_MAXT; ++tt) {
-#pragma unroll
-    for (int i = 0; i < R / 16; ++i) acc[tt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (wv + 4 * tt < ntiles) {
 #pragma unroll
       for (int s = 0; s < CH_MAXS; ++s) {
@@ -149,6 +179,19 @@ __device__ __forceinline__ void ch_mma(f32x4 (&acc)[CH_MAXT][R / 16], const bf16
   }
 }
 
+// wave-uniform dispatch on "the layer is 256 x 256"
+__device__ __forceinline__ void ch_fetch_any(bf16x8 (&bw)[CH_MAXT][CH_MAXS], const unsigned short *__restrict__ w, int rows,
+                                             int depth, int wv, int lane) {
+  if (rows == CH_W && depth == CH_W) ch_fetch<true>(bw, w, rows, depth, wv, lane);
+  else ch_fetch<false>(bw, w, rows, depth, wv, lane);
+}
+template <int R>
+__device__ __forceinline__ void ch_mma_any(f32x4 (&acc)[CH_MAXT][R / 16], const bf16x8 (&bw)[CH_MAXT][CH_MAXS],
+                                           const short (*X)[CH_XS], int rows, int depth, int wv, int l15, int quad) {
+  if (rows == CH_W && depth == CH_W) ch_mma<R, true>(acc, bw, X, rows, depth, wv, l15, quad);
+  else ch_mma<R, false>(acc, bw, X, rows, depth, wv, l15, quad);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------
@@ -156,36 +199,57 @@ template <int R>
 __global__ __launch_bounds__(256) void chain_fwd_kernel(const ChainFwdArgs a) {
   __shared__ short X[R][CH_XS];
   __shared__ float Y[R][CH_YS];
+  __shared__ ChainFwd desc;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, quad = lane >> 4;
-  int ci = 0;
-  for (int i = 1; i < a.nchains; ++i)
-    if ((int)blockIdx.x >= a.c[i].tile0) ci = i;
-  const ChainFwd &c = a.c[ci];
+  unsigned long long *stamps = (a.stamps && blockIdx.x == 0 && tid == 0) ? a.stamps : nullptr;
+  int nstamp = 0;
+#define CH_STAMP()                                                                   \
+  do {                                                                               \
+    if (stamps) {                                                                    \
+      stamps[2 * nstamp] = __builtin_amdgcn_s_memtime();                             \
+      stamps[2 * nstamp + 1] = __builtin_amdgcn_s_memrealtime();                     \
+      ++nstamp;                                                                      \
+    }                                                                                \
+  } while (0)
+  CH_STAMP();
+  const ChainFwd &c = ch_stage_desc(desc, a);
   const int M = c.M, r0 = ((int)blockIdx.x - c.tile0) * R;
+  CH_STAMP();
 
   bf16x8 bw[CH_MAXT][CH_MAXS];
-  ch_fetch(bw, c.L[0].w, c.L[0].N, c.L[0].K, wv, l15, quad);  // weights of the first layer fly during the input load
-
-  {  // input rows -> bf16 operand tile, zero-padded to a multiple of 32 columns
+  {  // input rows -> bf16 operand tile, zero-padded to a multiple of 32 columns.  Issue order: the input loads, THEN the
+     // first layer's weights (vector-memory results return in order: the tile can be built while the weights still fly)
     const int K0 = c.L[0].K, Kp = (K0 + 31) & ~31;
     const float *x0 = c.x0, *x1 = c.x1;
     float *xs = c.xsum;
     const bool vec = (K0 & 3) == 0 && (c.ldx0 & 3) == 0 && ((uintptr_t)x0 & 15) == 0 &&
                      (!x1 || ((c.ldx1 & 3) == 0 && ((uintptr_t)x1 & 15) == 0));
     if (vec) {
-      const int q = Kp >> 2;  // float4 per padded row
-      for (int idx = tid; idx < R * q; idx += 256) {
+      constexpr int IT = R * (CH_W / 4) / 256;  // float4 per thread for the widest input
+      const int q = Kp >> 2;                    // float4 per padded row
+      float4 v0[IT], v1[IT];
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int idx = tid + 256 * it;
         const int r = idx / q, col = (idx - r * q) * 4, row = r0 + r;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < M && col < K0) {
-          v = *reinterpret_cast<const float4 *>(x0 + (size_t)row * c.ldx0 + col);
-          if (x1) {
-            const float4 u = *reinterpret_cast<const float4 *>(x1 + (size_t)row * c.ldx1 + col);
-            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-            if (xs) *reinterpret_cast<float4 *>(xs + (size_t)row * K0 + col) = v;
-          }
+        const bool ok = idx < R * q && row < M && col < K0;
+        // branch-free: out-of-range threads re-read the first element of the tensor and discard it
+        v0[it] = *reinterpret_cast<const float4 *>(ok ? x0 + (size_t)row * c.ldx0 + col : x0);
+        v1[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (x1) v1[it] = *reinterpret_cast<const float4 *>(ok ? x1 + (size_t)row * c.ldx1 + col : x1);  // uniform branch
+      }
+      ch_fetch_any(bw, c.L[0].w, c.L[0].N, c.L[0].K, wv, lane);
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int idx = tid + 256 * it;
+        const int r = idx / q, col = (idx - r * q) * 4, row = r0 + r;
+        if (idx < R * q) {
+          const bool ok = row < M && col < K0;
+          float4 v = make_float4(v0[it].x + v1[it].x, v0[it].y + v1[it].y, v0[it].z + v1[it].z, v0[it].w + v1[it].w);
+          if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (xs && x1 && ok) *reinterpret_cast<float4 *>(xs + (size_t)row * K0 + col) = v;
+          *reinterpret_cast<short4 *>(&X[r][col]) = make_short4(ch_bf16(v.x), ch_bf16(v.y), ch_bf16(v.z), ch_bf16(v.w));
         }
-        *reinterpret_cast<short4 *>(&X[r][col]) = make_short4(ch_bf16(v.x), ch_bf16(v.y), ch_bf16(v.z), ch_bf16(v.w));
       }
     } else {
       for (int idx = tid; idx < R * Kp; idx += 256) {
@@ -200,61 +264,70 @@ __global__ __launch_bounds__(256) void chain_fwd_kernel(const ChainFwdArgs a) {
         }
         X[r][col] = ch_bf16(v);
       }
+      ch_fetch_any(bw, c.L[0].w, c.L[0].N, c.L[0].K, wv, lane);
     }
   }
 
   const int nl = c.nlayers;
+  const int c0 = 4 * lane;
   for (int l = 0; l < nl; ++l) {
     const ChainFwdLayer &L = c.L[l];
     const int K = L.K, N = L.N;
     const bool last = l + 1 == nl;
+    const bool relu = L.flags & 1u, ln = L.flags & 2u;
+    const int ntiles = (N + 15) >> 4;
+    // this layer's small parameters, issued before anything waits: bias of the wave's tiles, LayerNorm gamma / beta and
+    // the output scale of the lane's four columns (they land during the barrier and the MFMA phase)
+    float bv[CH_MAXT];
+#pragma unroll
+    for (int tt = 0; tt < CH_MAXT; ++tt) {
+      const int col = 16 * (wv + 4 * tt) + l15;
+      bv[tt] = L.bias ? L.bias[col < N ? col : 0] : 0.f;
+    }
+    float4 gm = make_float4(1.f, 1.f, 1.f, 1.f), bt = make_float4(0.f, 0.f, 0.f, 0.f), sc = gm;
+    if (ln) {  // uniform
+      if (L.gamma) gm = ch_ld4(L.gamma, c0, N);
+      if (L.beta) bt = ch_ld4(L.beta, c0, N);
+    }
+    if (last && c.out_scale) sc = ch_ld4(c.out_scale, c0, N);
+    CH_STAMP();
     __syncthreads();  // operand tile complete
+    CH_STAMP();
     f32x4 acc[CH_MAXT][R / 16];
-    ch_mma<R>(acc, bw, X, N, K, wv, l15, quad);
-    {  // bias (+ ReLU) -> fp32 result tile; element (i, r): row 16 i + 4 quad + r, column 16 t + l15
-      const int ntiles = (N + 15) >> 4;
-      const bool relu = L.flags & 1u;
+    ch_mma_any<R>(acc, bw, X, N, K, wv, l15, quad);
+    CH_STAMP();
+    // bias (+ ReLU) -> fp32 result tile; element (i, r): row 16 i + 4 quad + r, column 16 t + l15
 #pragma unroll
-      for (int tt = 0; tt < CH_MAXT; ++tt) {
-        const int t = wv + 4 * tt;
-        if (t < ntiles) {
-          const int col = 16 * t + l15;
-          const float bv = (L.bias && col < N) ? L.bias[col] : 0.f;
+    for (int tt = 0; tt < CH_MAXT; ++tt) {
+      const int t = wv + 4 * tt;
+      if (t < ntiles) {
+        const int col = 16 * t + l15;
 #pragma unroll
-          for (int i = 0; i < R / 16; ++i)
+        for (int i = 0; i < R / 16; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float v = acc[tt][i][r] + bv;
-              if (relu) v = fmaxf(v, 0.f);
-              Y[16 * i + 4 * quad + r][col] = v;
-            }
-        }
+          for (int r = 0; r < 4; ++r) {
+            float v = acc[tt][i][r] + bv[tt];
+            if (relu) v = fmaxf(v, 0.f);
+            Y[16 * i + 4 * quad + r][col] = v;
+          }
       }
     }
-    if (!last) ch_fetch(bw, c.L[l + 1].w, c.L[l + 1].N, c.L[l + 1].K, wv, l15, quad);  // lands during the row phase
+    CH_STAMP();
+    if (!last) ch_fetch_any(bw, c.L[l + 1].w, c.L[l + 1].N, c.L[l + 1].K, wv, lane);  // lands during the row phase
+    CH_STAMP();
     __syncthreads();  // result tile complete; operand tile free
+    CH_STAMP();
 
     // row phase: a wave walks rows wv, wv + 4, ...; lane owns columns 4 lane .. 4 lane + 3
-    const bool ln = L.flags & 2u;
-    const int c0 = 4 * lane;
     const bool n4 = (N & 3) == 0;
     const int Np = (N + 31) & ~31;
-    float4 gm = make_float4(1.f, 1.f, 1.f, 1.f), bt = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ln) {
-      if (c0 + 0 < N) { gm.x = L.gamma ? L.gamma[c0 + 0] : 1.f; bt.x = L.beta ? L.beta[c0 + 0] : 0.f; }
-      if (c0 + 1 < N) { gm.y = L.gamma ? L.gamma[c0 + 1] : 1.f; bt.y = L.beta ? L.beta[c0 + 1] : 0.f; }
-      if (c0 + 2 < N) { gm.z = L.gamma ? L.gamma[c0 + 2] : 1.f; bt.z = L.beta ? L.beta[c0 + 2] : 0.f; }
-      if (c0 + 3 < N) { gm.w = L.gamma ? L.gamma[c0 + 3] : 1.f; bt.w = L.beta ? L.beta[c0 + 3] : 0.f; }
-    }
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (last && c.out_scale) {
-      if (c0 + 0 < N) sc.x = c.out_scale[c0 + 0];
-      if (c0 + 1 < N) sc.y = c.out_scale[c0 + 1];
-      if (c0 + 2 < N) sc.z = c.out_scale[c0 + 2];
-      if (c0 + 3 < N) sc.w = c.out_scale[c0 + 3];
-    }
+    const float inv_n = 1.f / (float)N;
     float *sv = c.save;
-    for (int r = wv; r < R; r += 4) {
+    const unsigned off_h = L.off_h, off_y = L.off_y, off_stats = L.off_stats;
+    const float eps = L.eps;
+#pragma unroll
+    for (int j = 0; j < R / 4; ++j) {
+      const int r = wv + 4 * j;
       const int row = r0 + r;
       const bool rok = row < M;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -264,8 +337,8 @@ __global__ __launch_bounds__(256) void chain_fwd_kernel(const ChainFwdArgs a) {
         if (c0 + 2 >= N) v.z = 0.f;
         if (c0 + 3 >= N) v.w = 0.f;
       }
-      if (sv && L.off_h != CH_NONE && rok && c0 < N) {
-        float *h = sv + L.off_h + (size_t)row * N + c0;
+      if (sv && off_h != CH_NONE && rok && c0 < N) {
+        float *h = sv + off_h + (size_t)row * N + c0;
         if (n4) *reinterpret_cast<float4 *>(h) = v;
         else {
           h[0] = v.x;
@@ -275,10 +348,10 @@ __global__ __launch_bounds__(256) void chain_fwd_kernel(const ChainFwdArgs a) {
         }
       }
       if (ln) {
-        const float mean = wave_sum(v.x + v.y + v.z + v.w) / (float)N;
+        const float mean = wave_sum(v.x + v.y + v.z + v.w) * inv_n;
         float4 d = make_float4(c0 + 0 < N ? v.x - mean : 0.f, c0 + 1 < N ? v.y - mean : 0.f,
                                c0 + 2 < N ? v.z - mean : 0.f, c0 + 3 < N ? v.w - mean : 0.f);
-        const float rstd = rsqrtf(wave_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w) / (float)N + L.eps);
+        const float rstd = rsqrtf(wave_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w) * inv_n + eps);
         v = make_float4(d.x * rstd * gm.x + bt.x, d.y * rstd * gm.y + bt.y, d.z * rstd * gm.z + bt.z,
                         d.w * rstd * gm.w + bt.w);
         if (c0 + 1 >= N) v.y = 0.f;
@@ -286,12 +359,12 @@ __global__ __launch_bounds__(256) void chain_fwd_kernel(const ChainFwdArgs a) {
         if (c0 + 3 >= N) v.w = 0.f;
         if (c0 >= N) v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (sv && rok) {
-          if (L.off_stats != CH_NONE && lane == 0) {
-            sv[L.off_stats + 2 * (size_t)row] = mean;
-            sv[L.off_stats + 2 * (size_t)row + 1] = rstd;
+          if (off_stats != CH_NONE && lane == 0) {
+            sv[off_stats + 2 * (size_t)row] = mean;
+            sv[off_stats + 2 * (size_t)row + 1] = rstd;
           }
-          if (L.off_y != CH_NONE && c0 < N) {
-            float *y = sv + L.off_y + (size_t)row * N + c0;
+          if (off_y != CH_NONE && c0 < N) {
+            float *y = sv + off_y + (size_t)row * N + c0;
             if (n4) *reinterpret_cast<float4 *>(y) = v;
             else {
               y[0] = v.x;
@@ -335,24 +408,35 @@ __global__ __launch_bounds__(256) void chain_bwd_kernel(const ChainBwdArgs a) {
   __shared__ short X[R][CH_XS];   // bf16 dY of the current layer (MFMA A operand)
   __shared__ float G[R][CH_YS];   // fp32 gradient w.r.t. the current layer's output
   __shared__ float red[2][4][CH_W];
+  __shared__ ChainBwd desc;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, quad = lane >> 4;
-  int ci = 0;
-  for (int i = 1; i < a.nchains; ++i)
-    if ((int)blockIdx.x >= a.c[i].tile0) ci = i;
-  const ChainBwd &c = a.c[ci];
+  const ChainBwd &c = ch_stage_desc(desc, a);
   const int M = c.M, r0 = ((int)blockIdx.x - c.tile0) * R, nl = c.nlayers;
+  const int c0 = 4 * lane;
 
   bf16x8 bw[CH_MAXT][CH_MAXS];
-  if (nl > 1 || c.dx) ch_fetch(bw, c.L[nl - 1].wt, c.L[nl - 1].K, c.L[nl - 1].N, wv, l15, quad);
-
-  {  // incoming gradient rows -> G
+  {  // incoming gradient rows -> G (loads first, then the last layer's transposed weights, then the LDS stores)
     const int N = c.L[nl - 1].N;
-    for (int idx = tid; idx < R * N; idx += 256) {
-      const int r = idx / N, col = idx - r * N, row = r0 + r;
-      G[r][col] = row < M ? c.dout[(size_t)row * c.ldo + col] : 0.f;
+    const bool n4 = (N & 3) == 0 && (c.ldo & 3) == 0 && ((uintptr_t)c.dout & 15) == 0;
+    float4 g[R / 4];
+#pragma unroll
+    for (int j = 0; j < R / 4; ++j) {
+      const int row = r0 + wv + 4 * j;
+      const bool ok = row < M && c0 < N;
+      const float *p = c.dout + (size_t)(ok ? row : 0) * c.ldo;
+      if (n4) {
+        g[j] = *reinterpret_cast<const float4 *>(p + (ok ? c0 : 0));
+      } else {
+        g[j] = make_float4(p[c0 + 0 < N ? c0 + 0 : 0], p[c0 + 1 < N ? c0 + 1 : 0], p[c0 + 2 < N ? c0 + 2 : 0],
+                           p[c0 + 3 < N ? c0 + 3 : 0]);
+      }
+      if (!ok) g[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    if (nl > 1 || c.dx) ch_fetch_any(bw, c.L[nl - 1].wt, c.L[nl - 1].K, c.L[nl - 1].N, wv, lane);
+#pragma unroll
+    for (int j = 0; j < R / 4; ++j)
+      if (c0 < CH_W) *reinterpret_cast<float4 *>(&G[wv + 4 * j][c0]) = g[j];
   }
-  const int c0 = 4 * lane;
   for (int l = nl - 1; l >= 0; --l) {
     const ChainBwdLayer &L = c.L[l];
     const int K = L.K, N = L.N;
@@ -360,60 +444,68 @@ __global__ __launch_bounds__(256) void chain_bwd_kernel(const ChainBwdArgs a) {
     const bool relu = L.flags & 1u, ln = L.flags & 2u;
     const bool n4 = (N & 3) == 0;
     const int Np = (N + 31) & ~31;
-    __syncthreads();  // G complete
-    float4 gm = make_float4(1.f, 1.f, 1.f, 1.f), sc = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (ln && L.gamma) {
-      if (c0 + 0 < N) gm.x = L.gamma[c0 + 0];
-      if (c0 + 1 < N) gm.y = L.gamma[c0 + 1];
-      if (c0 + 2 < N) gm.z = L.gamma[c0 + 2];
-      if (c0 + 3 < N) gm.w = L.gamma[c0 + 3];
-    }
+    const float inv_n = 1.f / (float)N;
     const bool scaled = last && c.out_scale;
-    if (scaled) {
-      if (c0 + 0 < N) sc.x = c.out_scale[c0 + 0];
-      if (c0 + 1 < N) sc.y = c.out_scale[c0 + 1];
-      if (c0 + 2 < N) sc.z = c.out_scale[c0 + 2];
-      if (c0 + 3 < N) sc.w = c.out_scale[c0 + 3];
-    }
-    float4 pg = make_float4(0.f, 0.f, 0.f, 0.f), pb = pg, ps = pg;  // gamma / beta / scale gradient partials
+    const bool need_h = relu || ln || scaled;
     const float *sv = c.save;
-    for (int r = wv; r < R; r += 4) {
+    // everything the row phase reads from memory, issued before the barrier: gamma / scale of the lane's columns and,
+    // for each of the wave's rows, the saved activation h and the LayerNorm statistics
+    float4 gm = make_float4(1.f, 1.f, 1.f, 1.f), sc = gm;
+    if (ln && L.gamma) gm = ch_ld4(L.gamma, c0, N);
+    if (scaled) sc = ch_ld4(c.out_scale, c0, N);
+    float4 hs[R / 4];
+    float mu[R / 4], rs[R / 4];
+#pragma unroll
+    for (int j = 0; j < R / 4; ++j) {
+      const int row = r0 + wv + 4 * j;
+      const bool ok = row < M && c0 < N;
+      hs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      mu[j] = rs[j] = 0.f;
+      if (need_h) {  // uniform
+        const float *hp = sv + L.off_h + (size_t)(ok ? row : 0) * N;
+        if (n4) hs[j] = *reinterpret_cast<const float4 *>(hp + (ok ? c0 : 0));
+        else hs[j] = make_float4(hp[c0 + 0 < N ? c0 + 0 : 0], hp[c0 + 1 < N ? c0 + 1 : 0], hp[c0 + 2 < N ? c0 + 2 : 0],
+                                 hp[c0 + 3 < N ? c0 + 3 : 0]);
+        if (!ok) hs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c0 + 1 >= N) hs[j].y = 0.f;
+        if (c0 + 2 >= N) hs[j].z = 0.f;
+        if (c0 + 3 >= N) hs[j].w = 0.f;
+      }
+      if (ln) {  // uniform
+        const size_t so = L.off_stats + 2 * (size_t)(row < M ? row : 0);
+        mu[j] = sv[so];
+        rs[j] = sv[so + 1];
+      }
+    }
+    __syncthreads();  // G complete
+    float4 pg = make_float4(0.f, 0.f, 0.f, 0.f), pb = pg, ps = pg;  // gamma / beta / scale gradient partials
+#pragma unroll
+    for (int j = 0; j < R / 4; ++j) {
+      const int r = wv + 4 * j;
       const int row = r0 + r;
       const bool rok = row < M;
-      float4 g = make_float4(0.f, 0.f, 0.f, 0.f), h = g;
+      const float4 h = hs[j];
+      float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
       if (c0 < N) {
         g = *reinterpret_cast<const float4 *>(&G[r][c0]);
         if (c0 + 1 >= N) g.y = 0.f;
         if (c0 + 2 >= N) g.z = 0.f;
         if (c0 + 3 >= N) g.w = 0.f;
       }
-      if ((relu || ln || scaled) && rok && c0 < N) {
-        const float *hp = sv + L.off_h + (size_t)row * N + c0;
-        if (n4) h = *reinterpret_cast<const float4 *>(hp);
-        else {
-          h.x = hp[0];
-          if (c0 + 1 < N) h.y = hp[1];
-          if (c0 + 2 < N) h.z = hp[2];
-          if (c0 + 3 < N) h.w = hp[3];
-        }
-      }
+      if (!rok) g = make_float4(0.f, 0.f, 0.f, 0.f);
       if (scaled) {  // out = h * scale (+ residual)
         ps.x += g.x * h.x; ps.y += g.y * h.y; ps.z += g.z * h.z; ps.w += g.w * h.w;
         g.x *= sc.x; g.y *= sc.y; g.z *= sc.z; g.w *= sc.w;
       }
       if (ln) {
-        float mean = 0.f, rstd = 0.f;
-        if (rok) {
-          mean = sv[L.off_stats + 2 * (size_t)row];
-          rstd = sv[L.off_stats + 2 * (size_t)row + 1];
-        }
+        const float mean = mu[j], rstd = rs[j];
         float4 xh = make_float4(c0 + 0 < N ? (h.x - mean) * rstd : 0.f, c0 + 1 < N ? (h.y - mean) * rstd : 0.f,
                                 c0 + 2 < N ? (h.z - mean) * rstd : 0.f, c0 + 3 < N ? (h.w - mean) * rstd : 0.f);
         pg.x += g.x * xh.x; pg.y += g.y * xh.y; pg.z += g.z * xh.z; pg.w += g.w * xh.w;
         pb.x += g.x; pb.y += g.y; pb.z += g.z; pb.w += g.w;
         const float4 gh = make_float4(g.x * gm.x, g.y * gm.y, g.z * gm.z, g.w * gm.w);
-        const float m1 = wave_sum(gh.x + gh.y + gh.z + gh.w) / (float)N;
-        const float m2 = wave_sum(gh.x * xh.x + gh.y * xh.y + gh.z * xh.z + gh.w * xh.w) / (float)N;
+        const float m1 = wave_sum(gh.x + gh.y + gh.z + gh.w) * inv_n;
+        const float m2 = wave_sum(gh.x * xh.x + gh.y * xh.y + gh.z * xh.z + gh.w * xh.w) * inv_n;
         g = make_float4(rstd * (gh.x - m1 - xh.x * m2), rstd * (gh.y - m1 - xh.y * m2), rstd * (gh.z - m1 - xh.z * m2),
                         rstd * (gh.w - m1 - xh.w * m2));
         if (c0 + 0 >= N) g.x = 0.f;
@@ -465,7 +557,7 @@ __global__ __launch_bounds__(256) void chain_bwd_kernel(const ChainBwdArgs a) {
     if (need_dx) {
       // dX[r][k] = sum_n dY[r][n] Wt[k][n]: output columns k < K, reduction over n < N
       f32x4 acc[CH_MAXT][R / 16];
-      ch_mma<R>(acc, bw, X, K, N, wv, l15, quad);
+      ch_mma_any<R>(acc, bw, X, K, N, wv, l15, quad);
       const int ktiles = (K + 15) >> 4;
 #pragma unroll
       for (int tt = 0; tt < CH_MAXT; ++tt) {
@@ -483,9 +575,11 @@ __global__ __launch_bounds__(256) void chain_bwd_kernel(const ChainBwdArgs a) {
         }
       }
     }
-    if (l > 1 || (l == 1 && c.dx)) ch_fetch(bw, c.L[l - 1].wt, c.L[l - 1].K, c.L[l - 1].N, wv, l15, quad);
+    if (l > 1 || (l == 1 && c.dx)) ch_fetch_any(bw, c.L[l - 1].wt, c.L[l - 1].K, c.L[l - 1].N, wv, lane);
   }
 }
+
+static unsigned long long *g_stamps = nullptr;
 
 static int ch_check_dims(int K, int N) { return (K >= 1 && K <= CH_W && N >= 1 && N <= CH_W) ? 1 : 0; }
 
@@ -494,6 +588,8 @@ static int ch_check_dims(int K, int N) { return (K >= 1 && K <= CH_W && N >= 1 &
 using namespace hipad;
 
 extern "C" {
+
+void hipad_chain_debug_stamps(unsigned long long *device_buffer) { g_stamps = device_buffer; }
 
 int hipad_chain_forward(const hipad_chain *chains, int nchains, hipad_stream_t stream_) {
   if (!chains || nchains <= 0) return HIPAD_EINVAL;
@@ -506,6 +602,7 @@ int hipad_chain_forward(const hipad_chain *chains, int nchains, hipad_stream_t s
     ChainFwdArgs a;
     a.nchains = n;
     a.pad = 0;
+    a.stamps = g_stamps;
     int tiles = 0;
     for (int i = 0; i < n; ++i) {
       const hipad_chain &s = chains[base + i];
@@ -515,12 +612,13 @@ int hipad_chain_forward(const hipad_chain *chains, int nchains, hipad_stream_t s
       c.save = s.save;
       c.ldx0 = s.ldx0; c.ldx1 = s.ldx1; c.ldo = s.ldo; c.ldr = s.ldr;
       c.M = s.M; c.nlayers = s.nlayers; c.tile0 = tiles; c.pad = 0;
+      a.tile0[i] = tiles;
       tiles += (s.M + R - 1) / R;
       for (int l = 0; l < s.nlayers; ++l) {
         const hipad_chain_layer &sl = s.layers[l];
         if (!ch_check_dims(sl.K, sl.N) || !sl.w) return HIPAD_EINVAL;
         if (l > 0 && sl.K != s.layers[l - 1].N) return HIPAD_EINVAL;
-        if ((sl.K % 8 == 0) && ((uintptr_t)sl.w & 15)) return HIPAD_EINVAL;
+        if ((uintptr_t)sl.w & 15) return HIPAD_EINVAL;
         if ((sl.flags & 2) && l + 1 == s.nlayers && s.out_scale) return HIPAD_EINVAL;  // Scale after a LayerNorm: unused
         ChainFwdLayer &L = c.L[l];
         L.w = sl.w; L.bias = sl.bias; L.gamma = sl.gamma; L.beta = sl.beta;
@@ -554,12 +652,13 @@ int hipad_chain_backward_dx(const hipad_chain_grad *chains, int nchains, hipad_s
       ChainBwd &c = a.c[i];
       c.dout = s.dout; c.out_scale = s.out_scale; c.dscale = s.dscale; c.dx = s.dx; c.save = s.save; c.dy = s.dy;
       c.ldo = s.ldo; c.lddx = s.lddx; c.M = s.M; c.nlayers = s.nlayers; c.tile0 = tiles; c.pad = 0;
+      a.tile0[i] = tiles;
       tiles += (s.M + R - 1) / R;
       for (int l = 0; l < s.nlayers; ++l) {
         const hipad_chain_grad_layer &sl = s.layers[l];
         if (!ch_check_dims(sl.K, sl.N)) return HIPAD_EINVAL;
         const bool need_wt = l > 0 || s.dx;
-        if (need_wt && (!sl.wt || ((sl.N % 8 == 0) && ((uintptr_t)sl.wt & 15)))) return HIPAD_EINVAL;
+        if (need_wt && (!sl.wt || ((uintptr_t)sl.wt & 15))) return HIPAD_EINVAL;
         ChainBwdLayer &L = c.L[l];
         L.wt = sl.wt; L.gamma = sl.gamma; L.dgamma = sl.dgamma; L.dbeta = sl.dbeta;
         L.off_h = sl.off_h; L.off_stats = sl.off_stats; L.off_dy = sl.off_dy;

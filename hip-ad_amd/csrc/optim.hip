@@ -153,13 +153,18 @@ __global__ __launch_bounds__(256) void shadow_bf16_kernel(unsigned short *__rest
 
 __global__ void adamw_bump_kernel(int *step) { *step += 1; }
 
-// bf16 (and transposed bf16) copies of many fp32 matrices, one 32 x 32 tile per workgroup of 256 threads
+// bf16 copies of many fp32 matrices src = [R][C] in the MLP-chain operand layout (include/hipad.h): MFMA-fragment order.
+//   P(A [rows][depth]) : blocks of 16 rows x 32 depth, block (tr, s) at ((tr * S + s) * 512) elements, S = ceil(depth / 32);
+//                        inside a block lane = 16 * quad + l15 owns 8 consecutive elements A[16 tr + l15][32 s + 8 quad + j]
+//   dst = P(src) (rows = R, depth = C);  dst_t = P(src^T) (rows = C, depth = R); out-of-range elements are zero.
+// A wave then loads one block with ONE fully coalesced 1 KiB instruction (16 bytes per lane) straight into an MFMA B
+// fragment.  One 32 x 32 tile of src per workgroup of 256 threads (two blocks of each output).
 __global__ __launch_bounds__(256) void pack_weights_kernel(unsigned short *const *__restrict__ dst,
                                                            unsigned short *const *__restrict__ dst_t,
                                                            const float *const *__restrict__ src, const int *__restrict__ rows,
                                                            const int *__restrict__ cols, const int *__restrict__ tile_start,
                                                            int n_mats) {
-  __shared__ unsigned short T[32][33];
+  __shared__ unsigned short T[32][34];
   const int b = blockIdx.x;
   int lo = 0, hi = n_mats - 1;  // last matrix whose first tile is <= b
   while (lo < hi) {
@@ -170,23 +175,35 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(unsigned short *const
   const int tc = (C + 31) >> 5, t = b - tile_start[m];
   const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
   const float *s = src[m];
-  unsigned short *d = dst ? dst[m] : nullptr, *dt = dst_t[m];
+  unsigned short *d = dst ? dst[m] : nullptr, *dt = dst_t ? dst_t[m] : nullptr;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = r0 + ty + 8 * i, c = c0 + tx;
     unsigned short v = 0;
-    if (r < R && c < C) {
-      v = __builtin_bit_cast(unsigned short, (__bf16)s[(size_t)r * C + c]);
-      if (d) d[(size_t)r * C + c] = v;
-    }
+    if (r < R && c < C) v = __builtin_bit_cast(unsigned short, (__bf16)s[(size_t)r * C + c]);
     T[ty + 8 * i][tx] = v;
   }
   __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = c0 + ty + 8 * i, r = r0 + tx;
-    if (r < R && c < C) dt[(size_t)c * R + r] = T[tx][ty + 8 * i];
+  const int h = threadIdx.x >> 7, lane = (threadIdx.x >> 1) & 63, half = threadIdx.x & 1;
+  const int l15 = lane & 15, quad = lane >> 4;
+  if (d) {  // P(src): row tiles over R, steps over C
+    const int TR = (R + 15) >> 4, S = (C + 31) >> 5, tr = (r0 >> 4) + h, st = c0 >> 5;
+    if (tr < TR) {
+      ushort4 o;
+      const unsigned short *q = &T[16 * h + l15][8 * quad + 4 * half];
+      o.x = q[0]; o.y = q[1]; o.z = q[2]; o.w = q[3];
+      *reinterpret_cast<ushort4 *>(d + ((size_t)(tr * S + st) * 64 + lane) * 8 + 4 * half) = o;
+    }
+  }
+  if (dt) {  // P(src^T): row tiles over C, steps over R
+    const int TR = (C + 15) >> 4, S = (R + 31) >> 5, tr = (c0 >> 4) + h, st = r0 >> 5;
+    if (tr < TR) {
+      ushort4 o;
+      const int rr = 8 * quad + 4 * half, cc = 16 * h + l15;
+      o.x = T[rr + 0][cc]; o.y = T[rr + 1][cc]; o.z = T[rr + 2][cc]; o.w = T[rr + 3][cc];
+      *reinterpret_cast<ushort4 *>(dt + ((size_t)(tr * S + st) * 64 + lane) * 8 + 4 * half) = o;
+    }
   }
 }
 
@@ -205,7 +222,7 @@ float hipad_lr_factor(const hipad_lr_schedule *sched, int iteration) {
 
 int hipad_pack_weights(unsigned short *const *dst, unsigned short *const *dst_t, const float *const *src, const int *rows,
                        const int *cols, const int *tile_start, int n_mats, int total_tiles, hipad_stream_t stream) {
-  if (!dst_t || !src || !rows || !cols || !tile_start || n_mats <= 0 || total_tiles <= 0) return HIPAD_EINVAL;
+  if ((!dst && !dst_t) || !src || !rows || !cols || !tile_start || n_mats <= 0 || total_tiles <= 0) return HIPAD_EINVAL;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, dst, dst_t, src, rows, cols,
                      tile_start, n_mats);
   return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;

@@ -92,9 +92,6 @@ def surrogate_objective(model_outs, depths=None):
     return torch.stack(terms).sum()
 
 
-BF16_SHADOW = True  # keep a bf16 copy of the parameters current in the optimiser kernel (MFMA operand format)
-
-
 class TrainStep:
     """forward + objective + backward + gradient all-reduce + clip + AdamW step for one frame batch
     (optimiser settings of the reference: AdamW lr 2e-4 wd 1e-3, backbone lr x0.5, grad-clip 25,
@@ -116,7 +113,7 @@ class TrainStep:
         runner = cfg.get("runner") or {}
         self.opt = FlatAdamW([(rest, opt["lr"]), (bb, opt["lr"] * mult)], weight_decay=opt["weight_decay"],
                              max_norm=self.max_norm, comm_dtype=comm_dtype, lr_config=cfg.get("lr_config"),
-                             max_iters=int(runner.get("max_iters", 0)), bf16_shadow=BF16_SHADOW)
+                             max_iters=int(runner.get("max_iters", 0)))
         self.params = self.opt.params
         self.grads = self.opt.grads
         self._loosened = False

@@ -45,6 +45,7 @@ SIGNATURES = {
                          + [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p]),
     "hipad_lr_factor": (ctypes.c_float, [c_void_p, c_int]),
     "hipad_chain_forward": (c_int, [c_void_p, c_int, c_void_p]),
+    "hipad_chain_debug_stamps": (None, [c_void_p]),
     "hipad_chain_backward_dx": (c_int, [c_void_p, c_int, c_void_p]),
     "hipad_chain_backward_dw": (c_int, [c_void_p, c_int, c_void_p]),
     "hipad_pack_weights": (c_int, [c_void_p] * 6 + [c_int, c_int, c_void_p]),

@@ -61,7 +61,7 @@ class FlatAdamW:
     norm is left in ``self.grad_norm`` (device scalar).  State lives on the device: capturable."""
 
     def __init__(self, groups, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_norm=None, comm_dtype=None,
-                 lr_config=None, max_iters=0, bf16_shadow=False):
+                 lr_config=None, max_iters=0, bf16_shadow=False, chain_operands=True):
         if not 1 <= len(groups) <= 2:
             raise ValueError("one or two learning-rate groups")
         plists = [[p for p in ps if p.requires_grad] for ps, _ in groups]
@@ -93,15 +93,59 @@ class FlatAdamW:
         self._sched = schedule_struct(lr_config, max_iters)
         # bf16 copy of the flat parameter buffer, kept current by the AdamW kernel (operands of the MFMA kernels)
         self.shadow = None
+        self.offsets = offsets
         if bf16_shadow:
             self.shadow = torch.empty(total, dtype=torch.bfloat16, device=ref.device)
-            self.refresh_shadow()
-        self.offsets = offsets
+        self._pack = None
+        if chain_operands:
+            self._attach_chain_operands(ref.device)
+        self.refresh_shadow()
+
+    # ---- bf16 operand copies of the MLP-chain kernels -----------------------------------------------------
+    # Every 2-D parameter small enough for the chain kernels (both dims <= 256) gets two bf16 copies in their operand
+    # layout -- MFMA-fragment order of W and of W^T (include/hipad.h, hipad_pack_weights) -- refreshed from the fp32
+    # master by ONE pack launch per step.  Each such parameter carries ``_hipad_shadow = (w, wt)``,
+    # which hipad_amd.chain.bf16_pair prefers over its own version-keyed cache (the optimiser kernel updates
+    # parameters through raw pointers, invisible to torch's version counters).
+    def _attach_chain_operands(self, device):
+        mats = [p for p in self.params if p.dim() == 2 and max(p.shape) <= 256]
+        if not mats:
+            return
+        from .chain import packed_numel
+        total = sum(packed_numel(*p.shape) + packed_numel(p.shape[1], p.shape[0]) for p in mats)
+        self.chain_buf = torch.zeros(total, dtype=torch.bfloat16, device=device)
+        src, dst, dst_t, rows, cols, starts, tiles, off = [], [], [], [], [], [0], 0, 0
+        for p in mats:
+            n, k = p.shape
+            w = self.chain_buf[off:off + packed_numel(n, k)]
+            off += packed_numel(n, k)
+            wt = self.chain_buf[off:off + packed_numel(k, n)]
+            off += packed_numel(k, n)
+            p._hipad_shadow = (w, wt)
+            src.append(p.data_ptr()); dst.append(w.data_ptr()); dst_t.append(wt.data_ptr()); rows.append(n); cols.append(k)
+            tiles += ((n + 31) // 32) * ((k + 31) // 32)
+            starts.append(tiles)
+        i64 = lambda v: torch.tensor(v, dtype=torch.int64, device=device)  # noqa: E731
+        i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=device)  # noqa: E731
+        self._pack = dict(src=i64(src), dst=i64(dst), dst_t=i64(dst_t), rows=i32(rows), cols=i32(cols), starts=i32(starts),
+                          n=len(mats), tiles=tiles)
+
+    def _pack_chain_operands(self):
+        pk = self._pack
+        if pk is None:
+            return
+        lib = _lib.load()
+        dev = self.flat_p.device
+        with torch.cuda.device(dev):
+            _lib.check(lib.hipad_pack_weights(pk["dst"].data_ptr(), pk["dst_t"].data_ptr(), pk["src"].data_ptr(),
+                                              pk["rows"].data_ptr(), pk["cols"].data_ptr(), pk["starts"].data_ptr(), pk["n"],
+                                              pk["tiles"], _lib.stream_ptr(dev)), "hipad_pack_weights")
 
     def refresh_shadow(self):
-        """Re-derive the bf16 shadow from the fp32 parameters (after loading a checkpoint / writing p.data)."""
+        """Re-derive the bf16 copies from the fp32 parameters (after loading a checkpoint / writing p.data)."""
         if self.shadow is not None:
             _lib.shadow_bf16(self.shadow, self.flat_p)
+        self._pack_chain_operands()
 
     def shadow_of(self, p):
         """bf16 view of parameter ``p`` inside the shadow buffer (None when no shadow is kept)."""
@@ -121,3 +165,4 @@ class FlatAdamW:
         _lib.adamw_step(self.flat_p, self.grads.flat, self.exp_avg, self.exp_avg_sq, self.n_group0, self.lrs[0],
                         self.lrs[1], self.betas, self.eps, self.weight_decay, self.max_norm, self.step_count,
                         self._stats, self._ws, zero_grad=zero_grad, sched=self._sched, shadow=self.shadow)
+        self._pack_chain_operands()

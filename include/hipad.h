@@ -340,14 +340,15 @@ int hipad_adamw_step(float *param, float *grad, float *exp_avg, float *exp_avg_s
  * A chain: x = x0[r * ldx0 + c] (+ x1[r * ldx1 + c]); for every layer l: h = x W_l^T + b_l, ReLU if flags & 1,
  *   then x = LayerNorm(h) * gamma + beta if flags & 2 else x = h; out[r * ldo + c] = x * out_scale[c] +
  *   residual[r * ldr + c] for the last layer.  1 <= K, N <= 256; layer l + 1 has K = N of layer l.
- *   w: bf16 [N][K] row-major (16-byte aligned when K % 8 == 0); bias / gamma / beta fp32 or NULL.
+ *   w: the bf16 weights W [N][K] in MFMA-fragment order P(W) (see hipad_pack_weights, which makes them), 16-byte
+ *   aligned; bias / gamma / beta fp32 or NULL.
  * Training: `save` (fp32 scratch owned by the caller) receives, at the given float offsets, h (M x N: post-ReLU,
  *   pre-LayerNorm activation), y (M x N: LayerNorm output, only for flags & 2) and stats (M x 2: mean, rstd);
  *   xsum (M x K0, may be NULL) receives x0 + x1 when x1 is given.  With save == NULL nothing is kept (inference).
  * hipad_chain_backward_dx: reverse sweep.  dout (M rows, ldo) is the gradient of `out`; for every layer the gated
  *   gradient of its pre-activation is written to dy + off_dy (M x N) for hipad_chain_backward_dw, gamma / beta /
  *   out_scale gradients are ADDED atomically into dgamma / dbeta / dscale, and the input gradient is written to
- *   dx (M rows, lddx; NULL skips it).  wt: bf16 [K][N] (the transposed weights).
+ *   dx (M rows, lddx; NULL skips it).  wt: P(W^T), the transposed weights in fragment order.
  * hipad_chain_backward_dw: for every entry dw[N][K] += dy^T x, db[N] += column sums of dy (atomics; x: M rows, ldx).
  * ---------------------------------------------------------------------------------- */
 #define HIPAD_CHAIN_MAX_LAYERS 6
@@ -391,11 +392,18 @@ typedef struct hipad_chain_dw {
   int M, N, K, ldx;
 } hipad_chain_dw;
 int hipad_chain_forward(const hipad_chain *chains, int nchains, hipad_stream_t stream);
+/* Diagnostic aid: when set (>= 256 x 2 u64 of device memory), thread 0 of workgroup 0 of every forward launch writes
+ * (s_memtime, s_memrealtime) pairs at its phase boundaries there; NULL (the default) turns it off. */
+void hipad_chain_debug_stamps(unsigned long long *device_buffer);
 int hipad_chain_backward_dx(const hipad_chain_grad *chains, int nchains, hipad_stream_t stream);
 int hipad_chain_backward_dw(const hipad_chain_dw *entries, int nentries, hipad_stream_t stream);
-/* bf16 copies of a batch of fp32 matrices in one launch: dst_t[i][k][n] = bf16(src[i][n][k]) (transposed) and, where
- * dst[i] != NULL, dst[i][n][k] = bf16(src[i][n][k]).  All tables live in DEVICE memory: n_mats pointers / dimensions and
- * tile_start[n_mats + 1] = exclusive prefix sum of ceil(rows / 32) * ceil(cols / 32); total_tiles = its last entry. */
+/* The chains' operand copies of a batch of fp32 matrices src[i] = [rows][cols] in one launch, in MFMA-fragment order:
+ *   P(A [r][d]): blocks of 16 rows x 32 depth, block (tr, s) at element ((tr * ceil(d / 32) + s) * 512); inside a block
+ *   lane = 16 * quad + l15 (0..63) owns the 8 consecutive elements A[16 tr + l15][32 s + 8 quad + 0..7]; elements outside
+ *   A are zero.  Size: ceil(r / 16) * ceil(d / 32) * 512 bf16.
+ * dst[i] = P(src[i]) (the chains' `w`), dst_t[i] = P(src[i]^T) (their `wt`); either table may be NULL.  All tables live
+ * in DEVICE memory: n_mats pointers / dimensions and tile_start[n_mats + 1] = exclusive prefix sum of
+ * ceil(rows / 32) * ceil(cols / 32); total_tiles = its last entry. */
 int hipad_pack_weights(unsigned short *const *dst, unsigned short *const *dst_t, const float *const *src,
                        const int *rows, const int *cols, const int *tile_start, int n_mats, int total_tiles,
                        hipad_stream_t stream);

@@ -78,3 +78,24 @@ def test_flat_adamw_follows_the_lr_schedule_and_keeps_a_bf16_shadow():
         for p, q in zip(mine, ref):
             assert float((p - q).abs().max()) <= 3e-6 * max(1.0, float(q.abs().max())), step
             assert torch.equal(opt.shadow_of(p), p.detach().to(torch.bfloat16)), step
+
+
+def test_optimizer_keeps_the_chain_operands_current():
+    """After a step the fragment-ordered bf16 pair (W, W^T) attached to every small 2-D parameter equals the packed rounded
+    fp32 parameter -- the MLP-chain kernels read these copies, and the optimiser updates parameters behind torch's
+    back (no version-counter bump)."""
+    from hipad_amd import chain as CH
+    from hipad_amd.optim import FlatAdamW
+    ps = make_params(4)
+    opt = FlatAdamW([(ps[:4], 2e-3), (ps[4:], 1e-3)], weight_decay=1e-2, max_norm=1.0)
+    mats = [p for p in ps if p.dim() == 2 and max(p.shape) <= 256]
+    assert len(mats) == 3
+    for step in range(2):
+        for p in ps:
+            p.grad.copy_(torch.randn_like(p))
+        opt.step()
+        for p in mats:
+            w, wt = CH.bf16_pair(p)
+            assert w.data_ptr() == p._hipad_shadow[0].data_ptr()
+            assert torch.equal(w, CH.pack_fragments(p.detach()))
+            assert torch.equal(wt, CH.pack_fragments(p.detach().t()))
