@@ -53,9 +53,6 @@ class CDw(ctypes.Structure):
 # ------------------------------------------------------------------------------------------------------------
 # bf16 copies of the weights
 # ------------------------------------------------------------------------------------------------------------
-_shadow_cache = {}
-
-
 def pack_fragments(a):
     """P(A) of include/hipad.h (hipad_pack_weights): the bf16 copy of a 2-D matrix in MFMA-fragment order, zero-padded to
     16-row x 32-column blocks; block (tr, s), lane = 16 quad + l15 owns A[16 tr + l15][32 s + 8 quad + 0..7]."""
@@ -79,13 +76,14 @@ def bf16_pair(weight):
     pair = getattr(weight, "_hipad_shadow", None)
     if pair is not None:
         return pair
-    key = id(weight)
-    hit = _shadow_cache.get(key)
+    # cached ON the parameter object (a table keyed by id() would hand a new parameter that reuses a freed one's id,
+    # address, version and shape the old one's copies)
+    hit = getattr(weight, "_hipad_pair", None)
     stamp = (weight.data_ptr(), weight._version, tuple(weight.shape))
     if hit is None or hit[0] != stamp:
         w = weight.detach().float()
         hit = (stamp, pack_fragments(w), pack_fragments(w.t()))
-        _shadow_cache[key] = hit
+        weight._hipad_pair = hit
     return hit[1], hit[2]
 
 

@@ -39,11 +39,33 @@ class SparseBox3DEncoder(BaseModule):
         self.output_fc = mlp(widths[-1], widths[-1]) if output_fc else None
 
     def forward(self, box_3d: torch.Tensor):
+        from hipad_amd import chain as CH
+        if self.mode == "cat" and CH.usable(box_3d):
+            out = self._forward_chains(box_3d)
+            if out is not None:
+                return out
         parts = [self.pos_fc(box_3d[..., X:Z + 1]), self.size_fc(box_3d[..., W:H + 1]),
                  self.yaw_fc(box_3d[..., SIN_YAW:COS_YAW + 1])]
         if self.vel_dims > 0:
             parts.append(self.vel_fc(box_3d[..., VX:VX + self.vel_dims]))
         out = torch.cat(parts, dim=-1) if self.mode == "cat" else sum(parts[1:], parts[0])
+        return out if self.output_fc is None else self.output_fc(out)
+
+    def _forward_chains(self, box_3d):
+        """GPU path: the four part encoders as ONE chain launch writing the column ranges of one tensor ("cat" mode)."""
+        from hipad_amd import chain as CH
+        fcs = [(self.pos_fc, X, Z + 1), (self.size_fc, W, H + 1), (self.yaw_fc, SIN_YAW, COS_YAW + 1)]
+        if self.vel_dims > 0:
+            fcs.append((self.vel_fc, VX, VX + self.vel_dims))
+        specs = [CH.spec_of(m) for m, _, _ in fcs]
+        if any(sp is None for sp in specs):
+            return None
+        total = sum(sp.N_out for sp in specs)
+        calls, col = [], 0
+        for sp, (_, lo, hi) in zip(specs, fcs):
+            calls.append(CH.Call(sp, box_3d[..., lo:hi], out_slot=(0, col), out_width=total))
+            col += sp.N_out
+        (out,) = CH.run(calls)
         return out if self.output_fc is None else self.output_fc(out)
 
 
@@ -72,8 +94,29 @@ class SparseBox3DRefinementModule(BaseModule):
             nn.init.constant_(self.cls_layers[-1].bias, bias_init_with_prob(0.01))
 
     def forward(self, instance_feature, anchor, anchor_embed, time_interval=1.0, return_cls=True):
-        feature = instance_feature + anchor_embed
-        delta = self.layers(feature)
+        from hipad_amd import chain as CH
+        cls = quality = grouped = None
+        if CH.usable(instance_feature):
+            # the regression, class and quality stacks as ONE chain launch (the input sum inside the kernel)
+            specs = [CH.spec_of(self.layers)]
+            if return_cls and self.with_cls_branch:
+                specs.append(CH.spec_of(self.cls_layers))
+                if self.with_quality_estimation:
+                    specs.append(CH.spec_of(self.quality_layers))
+            if all(sp is not None for sp in specs):
+                calls = [CH.Call(specs[0], instance_feature, anchor_embed)]
+                if len(specs) > 1:
+                    calls.append(CH.Call(specs[1], instance_feature))
+                if len(specs) > 2:
+                    calls.append(CH.Call(specs[2], instance_feature, anchor_embed))
+                grouped = CH.run(calls)
+        if grouped is not None:
+            delta = grouped[0]
+            cls = grouped[1] if len(grouped) > 1 else None
+            quality = grouped[2] if len(grouped) > 2 else None
+        else:
+            feature = instance_feature + anchor_embed
+            delta = self.layers(feature)
         n_state = len(self.refine_state)  # the refined columns are the leading ones: X..H (+ yaw)
         head = delta[..., :n_state] + anchor[..., :n_state]
         pieces = [head]
@@ -90,13 +133,14 @@ class SparseBox3DRefinementModule(BaseModule):
             dt = time_interval.reshape(-1, *([1] * (delta.dim() - 1))) if time_interval.dim() else time_interval
             pieces.append(delta[..., VX:] / dt + anchor[..., VX:])
         output = torch.cat(pieces, dim=-1)
-        cls = quality = None
-        if return_cls:
+        if return_cls and grouped is None:
             if not self.with_cls_branch:
                 raise AssertionError("Without classification layers !!!")
             cls = self.cls_layers(instance_feature)
             if self.with_quality_estimation:
                 quality = self.quality_layers(feature)
+        elif return_cls and not self.with_cls_branch:
+            raise AssertionError("Without classification layers !!!")
         return output, cls, quality
 
 

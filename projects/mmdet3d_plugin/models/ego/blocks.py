@@ -23,7 +23,7 @@ class EgoStatusRefinementModule(BaseModule):
         self.plan_status_branch = mlp_head(embed_dims, status_dims)
 
     def forward(self, ego_feature, ego_anchor_embed):
-        return self.plan_status_branch(ego_anchor_embed + ego_feature)
+        return self.plan_status_branch(ego_anchor_embed, ego_feature)  # the sum happens inside the chain kernel
 
 
 @PLUGIN_LAYERS.register_module()

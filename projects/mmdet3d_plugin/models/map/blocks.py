@@ -74,12 +74,20 @@ class SparsePoint3DRefinementModule(BaseModule):
             nn.init.constant_(self.cls_layers[-1].bias, bias_init_with_prob(0.01))
 
     def forward(self, instance_feature, anchor, anchor_embed, time_interval=1.0, return_cls=True):
+        from hipad_amd import chain as CH
+        if return_cls and not self.with_cls_branch:
+            raise AssertionError("Without classification layers !!!")
+        if CH.usable(instance_feature):
+            # both stacks as ONE chain launch; input sum and the residual anchor inside the kernel
+            specs = [CH.spec_of(self.layers)] + ([CH.spec_of(self.cls_layers)] if return_cls else [])
+            if all(sp is not None for sp in specs):
+                calls = [CH.Call(specs[0], instance_feature, anchor_embed, residual=anchor)]
+                if return_cls:
+                    calls.append(CH.Call(specs[1], instance_feature))
+                outs = CH.run(calls)
+                return outs[0], (outs[1] if return_cls else None), None
         output = self.layers(instance_feature + anchor_embed) + anchor
-        cls = None
-        if return_cls:
-            if not self.with_cls_branch:
-                raise AssertionError("Without classification layers !!!")
-            cls = self.cls_layers(instance_feature)
+        cls = self.cls_layers(instance_feature) if return_cls else None
         return output, cls, None
 
 

@@ -30,7 +30,12 @@ class SparseMotionRefinementModule(BaseModule):
         nn.init.constant_(last.bias, bias_init_with_prob(0.01))
 
     def forward(self, motion_query):
+        from hipad_amd import chain as CH
         lead = motion_query.shape[:2]
+        specs = (CH.spec_of(self.motion_cls_branch), CH.spec_of(self.motion_reg_branch)) if CH.usable(motion_query) else (None,)
+        if all(sp is not None for sp in specs):  # both heads as ONE chain launch
+            scores, steps = CH.run([CH.Call(specs[0], motion_query), CH.Call(specs[1], motion_query)])
+            return scores[..., 0], steps.reshape(*lead, self.fut_mode, self.fut_ts, 2)
         scores = self.motion_cls_branch(motion_query)[..., 0]
         steps = self.motion_reg_branch(motion_query)
         return scores, steps.reshape(*lead, self.fut_mode, self.fut_ts, 2)

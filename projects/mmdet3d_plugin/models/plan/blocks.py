@@ -31,6 +31,12 @@ class SparsePlanRefinementModule(BaseModule):
         nn.init.constant_(self.plan_cls_branch[-1].bias, bias_init_with_prob(0.01))
 
     def forward(self, instance_feature, anchor, anchor_embed, use_plan_anchor_embed=True):
+        from hipad_amd import chain as CH
+        if CH.usable(instance_feature):
+            specs = (CH.spec_of(self.plan_reg_branch), CH.spec_of(self.plan_cls_branch))
+            if all(sp is not None for sp in specs):  # both stacks as ONE chain launch, input sum + residual anchor inside
+                return CH.run([CH.Call(specs[0], instance_feature, anchor_embed if use_plan_anchor_embed else None,
+                                       residual=anchor), CH.Call(specs[1], instance_feature)])
         src = instance_feature + anchor_embed if use_plan_anchor_embed else instance_feature
         return self.plan_reg_branch(src) + anchor, self.plan_cls_branch(instance_feature)
 
@@ -72,6 +78,47 @@ class SparsePlanAlignRefinementModule(BaseModule):
         if hasattr(self, "plan_cls_branch_speed"):
             nn.init.constant_(self.plan_cls_branch_speed[-1].bias, prior)
 
+    def _forward_chains(self, aligned, speed_sources, areas, anchor):
+        """GPU path: every distinct (branch, input) pair of the module as one chain of ONE grouped launch (eight chains
+        for the ten anchor types of the HiP-AD configs) instead of ~50 Linear / LayerNorm launches on 48..144 rows."""
+        from hipad_amd import chain as CH
+        speed_in = torch.cat(speed_sources, dim=1) if len(speed_sources) > 1 else (speed_sources[0] if speed_sources else None)
+        calls, index = [], {}
+
+        def add(module, key, x):
+            k = (id(module), key)
+            if k not in index:
+                spec = CH.spec_of(module)
+                if spec is None:
+                    return False
+                index[k] = len(calls)
+                calls.append(CH.Call(spec, x))
+            return True
+
+        plan = []
+        for t in self.anchor_types:
+            branch = getattr(self, f"plan_reg_branch_{t[0]}_{t[1]}")
+            if t[0] in ("temp", "spat"):
+                ok = add(branch, "aligned", aligned) and add(self.plan_cls_branch, "aligned", aligned)
+                plan.append(((id(branch), "aligned"), (id(self.plan_cls_branch), "aligned"), None))
+            elif t[0] == "speed":
+                ok = add(branch, "speed", speed_in) and add(self.plan_cls_branch_speed, "speed", speed_in)
+                plan.append(((id(branch), "speed"), (id(self.plan_cls_branch_speed), "speed"), areas.index(t[2])))
+            else:
+                raise NotImplementedError(t[0])
+            if not ok:
+                return None
+        outs = CH.run(calls)
+        regs, scores = [], []
+        n_area = max(1, len(areas))
+        for rk, sk, area in plan:
+            r, sc = outs[index[rk]], outs[index[sk]]
+            if area is not None:
+                r, sc = r.chunk(n_area, dim=1)[area], sc.chunk(n_area, dim=1)[area]
+            regs.append(r)
+            scores.append(sc)
+        return torch.cat(regs, dim=1) + anchor, torch.cat(scores, dim=1)
+
     def forward(self, instance_feature, anchor, anchor_embed, use_plan_anchor_embed=True):
         if use_plan_anchor_embed:
             instance_feature = instance_feature + anchor_embed
@@ -87,6 +134,11 @@ class SparsePlanAlignRefinementModule(BaseModule):
         # of the speed groups that share an interval).  Evaluate every distinct (module, input) once and
         # stack the inputs of a shared module into one call.
         areas = list(speed_query)
+        from hipad_amd import chain as CH
+        if CH.usable(instance_feature):
+            out = self._forward_chains(aligned, [speed_query[a] for a in areas], areas, anchor)
+            if out is not None:
+                return out
         cache = {}
 
         def run(module, key, sources):
