@@ -165,38 +165,55 @@ def spec_of(seq):
     return spec
 
 
+class OutSlot:
+    """Placement of a chain's output inside a tensor shared by several calls of one group: the chain writes rows
+    [row0, row0 + M) and columns [col0, col0 + N) of the tensor ``key`` (any hashable) of full shape ``shape``."""
+
+    __slots__ = ("key", "shape", "row0", "col0")
+
+    def __init__(self, key, shape, row0=0, col0=0):
+        self.key, self.shape, self.row0, self.col0 = key, tuple(shape), row0, col0
+
+
 class Call:
-    """One chain invocation: out = spec(x0 (+ x1)) (+ residual).  ``out_slot`` = (index of a shared output tensor,
-    first column) when several calls write column ranges of one tensor (concatenated encoders)."""
+    """One chain invocation: out = spec(x0 (+ x1)) * scale (+ residual).
 
-    __slots__ = ("spec", "x0", "x1", "residual", "out_slot", "out_width")
+    x0_cols = (lo, hi): the chain reads columns [lo, hi) of ``x0`` (a parent tensor such as the 11-column box anchors); the
+                        input gradients of all calls of the group that read the same parent land in ONE gradient tensor.
+    scale:              per-column output factor replacing the stack's own trailing Scale parameter (any tensor, e.g.
+                        the parameter times a per-frame constant); its gradient is returned to autograd.
+    out_slot:           OutSlot when several calls fill parts of one tensor (concatenated encoders, stacked heads)."""
 
-    def __init__(self, spec, x0, x1=None, residual=None, out_slot=None, out_width=None):
-        self.spec, self.x0, self.x1, self.residual, self.out_slot, self.out_width = spec, x0, x1, residual, out_slot, out_width
+    __slots__ = ("spec", "x0", "x1", "residual", "out_slot", "x0_cols", "scale")
+
+    def __init__(self, spec, x0, x1=None, residual=None, out_slot=None, x0_cols=None, scale=None):
+        self.spec, self.x0, self.x1, self.residual = spec, x0, x1, residual
+        self.out_slot, self.x0_cols, self.scale = out_slot, x0_cols, scale
 
 
-def _rows_view(t, width):
-    """(tensor usable as M rows of `width` floats with a uniform row stride, M, ld)."""
+def _rows_view(t, width, cols=None):
+    """(tensor usable as M rows with a uniform row stride, M, ld): rows of ``width`` floats, or -- with ``cols`` =
+    (lo, hi) -- rows of a wider parent of which the caller reads columns lo..hi."""
     if t.dtype != torch.float32:
         t = t.float()
-    if t.shape[-1] != width:
-        raise _lib.HipadError(f"chain: input width {t.shape[-1]} != layer width {width}")
+    full = t.shape[-1]
+    if cols is None and full != width:
+        raise _lib.HipadError(f"chain: input width {full} != layer width {width}")
     ok = t.dim() >= 1 and t.stride(-1) == 1
+    ld = full
     if ok and t.dim() >= 2:
-        ld = t.stride(-2) if t.shape[-2] > 1 else max(width, 1)
+        ld = t.stride(-2) if t.shape[-2] > 1 else max(full, 1)
         for d in range(t.dim() - 3, -1, -1):
             if t.shape[d] != 1 and t.stride(d) != t.stride(d + 1) * t.shape[d + 1]:
                 ok = False
         if t.dim() >= 3 and t.shape[-2] == 1:
             ok = False  # degenerate row dim: let contiguous() sort it out
-        if ld < width:
+        if ld < full:
             ok = False
-    elif ok:
-        ld = width
     if not ok:
         t = t.contiguous()
-        ld = width
-    M = t.numel() // width
+        ld = full
+    M = t.numel() // full
     return t, M, ld
 
 
@@ -204,7 +221,7 @@ def _acc_target(p, rets, i):
     """In-place accumulation target for parameter ``p`` (its .grad when that is a contiguous fp32 buffer) or a fresh
     zero tensor that is returned to autograd instead."""
     from . import functional as HF
-    g = p.grad if HF.LINEAR_INPLACE_GRAD else None
+    g = p.grad if (HF.LINEAR_INPLACE_GRAD and p.is_leaf) else None
     if g is not None and g.is_contiguous() and g.dtype == torch.float32:
         HF.INPLACE_PARAMS.add(id(p))
         return g
@@ -212,56 +229,68 @@ def _acc_target(p, rets, i):
     return rets[i]
 
 
+def _prod(shape):
+    n = 1
+    for v in shape:
+        n *= int(v)
+    return n
+
+
 class _Chains(Function):
+    """forward(meta, *tensors): per call the tensors x0, x1, residual, (weight, bias, gamma, beta) per layer, scale."""
+
     @staticmethod
     def forward(ctx, meta, *tensors):
-        calls, n_out = meta          # calls: list of (spec, out_slot, out_width); tensors: x0, x1, residual, params ...
+        calls, slot_keys = meta     # calls: [(spec, out_slot, x0_cols)], slot_keys: ordered keys of the shared outputs
         lib = _lib.load()
         dev = tensors[0].device
         need_grad = any(ctx.needs_input_grad[1:])
         arr = (CChain * len(calls))()
-        outs = [None] * n_out
-        keep = []          # python references that must outlive the launch / the backward
-        rec = []           # per call: dict for backward
+        shared = {}        # key -> tensor (rows_total, width)
+        private = []       # outputs of calls without a slot, in call order
+        keep, rec = [], []
         pos = 0
-        for ci, (spec, out_slot, out_width) in enumerate(calls):
+        for ci, (spec, slot, x0_cols) in enumerate(calls):
             x0, x1, res = tensors[pos:pos + 3]
-            nparam = 4 * len(spec.layers) + 1
+            nl = len(spec.layers)
+            nparam = 4 * nl + 1
             params = tensors[pos + 3:pos + 3 + nparam]
             pin = pos
             pos += 3 + nparam
-            K0 = spec.K0
-            x0v, M, ld0 = _rows_view(x0, K0)
+            K0, N_out = spec.K0, spec.N_out
+            x0v, M, ld0 = _rows_view(x0, K0, x0_cols)
+            lo = 0 if x0_cols is None else x0_cols[0]
+            if x0_cols is not None and x0_cols[1] - x0_cols[0] != K0:
+                raise _lib.HipadError("chain: x0_cols width differs from the first layer's input width")
             x1v = ld1 = None
             if x1 is not None:
                 x1v, M1, ld1 = _rows_view(x1, K0)
                 if M1 != M:
                     raise _lib.HipadError("chain: x0 and x1 differ in rows")
-            N_out = spec.N_out
-            if out_slot is None:
+            if slot is None:
                 out = torch.empty(M, N_out, dtype=torch.float32, device=dev)
-                oslot, ocol, ldo = ci, 0, N_out
-                outs[ci] = out
-                out_ptr = out.data_ptr()
+                private.append(out.view(*x0.shape[:-1], N_out))
+                out_ptr, ldo, row0, col0 = out.data_ptr(), N_out, 0, 0
             else:
-                oslot, ocol = out_slot
-                if outs[oslot] is None:
-                    outs[oslot] = torch.empty(M, out_width, dtype=torch.float32, device=dev)
-                out = outs[oslot]
-                ldo = out.shape[1]
-                out_ptr = out.data_ptr() + 4 * ocol
+                width = slot.shape[-1]
+                if slot.key not in shared:
+                    shared[slot.key] = torch.empty(_prod(slot.shape[:-1]), width, dtype=torch.float32, device=dev)
+                out = shared[slot.key]
+                row0, col0, ldo = slot.row0, slot.col0, width
+                if row0 + M > out.shape[0] or col0 + N_out > width:
+                    raise _lib.HipadError("chain: output slot out of range")
+                out_ptr = out.data_ptr() + 4 * (row0 * width + col0)
             resv = ldr = None
             if res is not None:
                 resv, Mr, ldr = _rows_view(res, N_out)
                 if Mr != M:
                     raise _lib.HipadError("chain: residual differs in rows")
-            # saved activations
+            scale = params[-1]
             offs, total = [], 0
-            nl = len(spec.layers)
             for li, L in enumerate(spec.layers):
                 N = L.weight.shape[0]
                 last = li + 1 == nl
-                need_h = need_grad and ((not last) or L.relu or L.ln is not None or spec.scale is not None)
+                need_h = need_grad and ((not last) or L.relu or L.ln is not None or scale is not None)
                 oh = oy = ost = NONE
                 if need_h:
                     oh, total = total, total + M * N
@@ -272,11 +301,13 @@ class _Chains(Function):
             save = torch.empty(max(total, 1), dtype=torch.float32, device=dev) if need_grad else None
             xsum = torch.empty(M, K0, dtype=torch.float32, device=dev) if (need_grad and x1 is not None) else None
             c = arr[ci]
-            c.x0, c.x1 = x0v.data_ptr(), (x1v.data_ptr() if x1v is not None else None)
+            c.x0 = x0v.data_ptr() + 4 * lo
+            c.x1 = x1v.data_ptr() if x1v is not None else None
             c.xsum = xsum.data_ptr() if xsum is not None else None
             c.out = out_ptr
-            scale = params[-1]
             c.out_scale = scale.data_ptr() if scale is not None else None
+            if scale is not None and (scale.dtype != torch.float32 or not scale.is_contiguous() or scale.numel() != N_out):
+                raise _lib.HipadError("chain: scale must be a contiguous fp32 vector of the output width")
             c.residual = resv.data_ptr() if resv is not None else None
             c.save = save.data_ptr() if save is not None else None
             c.ldx0, c.ldx1, c.ldo, c.ldr = ld0, (ld1 or 0), ldo, (ldr or 0)
@@ -284,10 +315,10 @@ class _Chains(Function):
             shadows = []
             for li, L in enumerate(spec.layers):
                 w, b, g, bt = params[4 * li:4 * li + 4]
-                wb, wtb = bf16_pair(L.weight)
-                shadows.append((wb, wtb))
+                pair = bf16_pair(L.weight)
+                shadows.append(pair)
                 cl = c.layers[li]
-                cl.w = wb.data_ptr()
+                cl.w = pair[0].data_ptr()
                 cl.bias = b.data_ptr() if b is not None else None
                 cl.gamma = g.data_ptr() if g is not None else None
                 cl.beta = bt.data_ptr() if bt is not None else None
@@ -295,81 +326,95 @@ class _Chains(Function):
                 cl.N, cl.K = L.weight.shape
                 cl.flags = (1 if L.relu else 0) | (2 if L.ln is not None else 0)
                 cl.eps = float(L.ln.eps) if L.ln is not None else 0.0
-            keep.append((x0v, x1v, resv, shadows))
-            rec.append(dict(spec=spec, M=M, ld0=ld0, x0v=x0v, xsum=xsum, save=save, offs=offs, oslot=oslot, ocol=ocol,
-                            pin=pin, x0_shape=tuple(x0.shape), x1_shape=None if x1 is None else tuple(x1.shape),
-                            res_shape=None if res is None else tuple(res.shape), shadows=shadows))
+            keep.append((x0v, x1v, resv, shadows, scale))
+            rec.append(dict(spec=spec, M=M, ld0=ld0, lo=lo, x0v=x0v, xsum=xsum, save=save, offs=offs, slot=slot, pin=pin,
+                            x0_shape=tuple(x0.shape), x0_cols=x0_cols, x0_id=id(x0),
+                            x1_shape=None if x1 is None else tuple(x1.shape),
+                            res_shape=None if res is None else tuple(res.shape), shadows=shadows, scale=scale))
         with torch.cuda.device(dev):
             _lib.check(lib.hipad_chain_forward(arr, len(calls), _lib.stream_ptr(dev)), "hipad_chain_forward")
-        ctx.rec, ctx.n_in = rec, len(tensors)
-        ctx.keep = keep
-        results = []
-        for ci, (spec, out_slot, out_width) in enumerate(calls):
-            if out_slot is None:
-                r = rec[ci]
-                results.append(outs[ci].view(*r["x0_shape"][:-1], spec.N_out))
-        # shared (concatenated) outputs come after the private ones, in slot order
-        shared = sorted({r["oslot"] for r, (s, o, w) in zip(rec, calls) if o is not None})
-        for slot in shared:
-            r = next(r for r, (s, o, w) in zip(rec, calls) if o is not None and r["oslot"] == slot)
-            results.append(outs[slot].view(*r["x0_shape"][:-1], outs[slot].shape[1]))
-        ctx.order = ([ci for ci, (s, o, w) in enumerate(calls) if o is None], shared)
-        ctx.calls = calls
+        ctx.rec, ctx.n_in, ctx.keep, ctx.calls, ctx.slot_keys = rec, len(tensors), keep, calls, slot_keys
+        results = list(private)
+        for key in slot_keys:
+            shape = next(slot.shape for (_, slot, _) in calls if slot is not None and slot.key == key)
+            results.append(shared[key].view(shape))
         return tuple(results)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, *gouts):
         lib = _lib.load()
-        calls, rec = ctx.calls, ctx.rec
-        private, shared = ctx.order
-        dev = gouts[0].device if gouts[0] is not None else rec[0]["x0v"].device
+        calls, rec, slot_keys = ctx.calls, ctx.rec, ctx.slot_keys
+        dev = rec[0]["x0v"].device
         grads = [None] * (ctx.n_in + 1)      # +1: meta
-        gmap = {}
-        for k, ci in enumerate(private):
-            gmap[("p", ci)] = gouts[k]
-        for k, slot in enumerate(shared):
-            gmap[("s", slot)] = gouts[len(private) + k]
+        n_private = sum(1 for (_, slot, _) in calls if slot is None)
+        gshared = {}
+        for k, key in enumerate(slot_keys):
+            g = gouts[n_private + k]
+            shape = next(slot.shape for (_, slot, _) in calls if slot is not None and slot.key == key)
+            rows, width = _prod(shape[:-1]), shape[-1]
+            if g is None:
+                g = torch.zeros(rows, width, dtype=torch.float32, device=dev)
+            g = g.reshape(rows, width)
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                g = g.float().contiguous()
+            gshared[key] = g
         garr = (CChainGrad * len(calls))()
-        dws = []
-        keep = []
-        for ci, ((spec, out_slot, out_width), r) in enumerate(zip(calls, rec)):
-            M, nl = r["M"], len(spec.layers)
-            N_out = spec.N_out
-            if out_slot is None:
-                g = gmap[("p", ci)]
+        dws, keep, parents = [], [], {}
+        pi = 0
+        for ci, ((spec, slot, x0_cols), r) in enumerate(zip(calls, rec)):
+            M, nl, N_out = r["M"], len(spec.layers), spec.N_out
+            if slot is None:
+                g = gouts[pi]
+                pi += 1
                 if g is None:
                     g = torch.zeros(M, N_out, dtype=torch.float32, device=dev)
                 g2 = g.reshape(M, N_out)
-                if g2.dtype != torch.float32 or g2.stride(-1) != 1 or g2.stride(0) < N_out:
+                if g2.dtype != torch.float32 or g2.stride(-1) != 1 or (M > 1 and g2.stride(0) < N_out):
                     g2 = g2.float().contiguous()
-                dout_ptr, ldo = g2.data_ptr(), g2.stride(0) if M > 1 else N_out
+                dout_ptr, ldo = g2.data_ptr(), (g2.stride(0) if M > 1 else N_out)
+                gres = g2
             else:
-                g = gmap[("s", r["oslot"])]
-                width = out_width
-                if g is None:
-                    g = torch.zeros(M, width, dtype=torch.float32, device=dev)
-                g2 = g.reshape(M, width)
-                if g2.dtype != torch.float32 or not g2.is_contiguous():
-                    g2 = g2.float().contiguous()
-                dout_ptr, ldo = g2.data_ptr() + 4 * r["ocol"], width
+                g2 = gshared[slot.key]
+                width = g2.shape[1]
+                dout_ptr, ldo = g2.data_ptr() + 4 * (slot.row0 * width + slot.col0), width
+                gres = g2[slot.row0:slot.row0 + M, slot.col0:slot.col0 + N_out]
             keep.append(g2)
             pin = r["pin"]
             need_x = ctx.needs_input_grad[1 + pin] or (r["x1_shape"] is not None and ctx.needs_input_grad[2 + pin])
             dy_total = sum(M * L.weight.shape[0] for L in spec.layers)
             dy = torch.empty(dy_total, dtype=torch.float32, device=dev)
-            dx = torch.empty(M, spec.K0, dtype=torch.float32, device=dev) if need_x else None
-            rets = [None] * (4 * nl + 1)
+            dx = None
             c = garr[ci]
+            if need_x and x0_cols is None:
+                dx = torch.empty(M, spec.K0, dtype=torch.float32, device=dev)
+                c.dx, c.lddx = dx.data_ptr(), spec.K0
+            elif need_x:
+                # calls reading column ranges of one parent share its gradient tensor
+                ent = parents.get(r["x0_id"])
+                if ent is None:
+                    D = r["x0_shape"][-1]
+                    covered = sorted(rr["x0_cols"] for rr in rec if rr["x0_id"] == r["x0_id"] and rr["x0_cols"] is not None)
+                    full, end = True, 0
+                    for lo_, hi_ in covered:
+                        full, end = full and lo_ <= end, max(end, hi_)
+                    full = full and end >= D
+                    buf = (torch.empty if full else torch.zeros)(M, D, dtype=torch.float32, device=dev)
+                    ent = parents[r["x0_id"]] = buf
+                    grads[1 + pin] = buf.view(r["x0_shape"])
+                c.dx, c.lddx = ent.data_ptr() + 4 * r["lo"], ent.shape[1]
+            else:
+                c.dx, c.lddx = None, spec.K0
+            rets = [None] * (4 * nl + 1)
+            scale = r["scale"]
             c.dout = dout_ptr
-            c.out_scale = spec.scale.data_ptr() if spec.scale is not None else None
+            c.out_scale = scale.data_ptr() if scale is not None else None
             c.dscale = None
-            if spec.scale is not None and ctx.needs_input_grad[1 + pin + 3 + 4 * nl]:
-                c.dscale = _acc_target(spec.scale, rets, 4 * nl).data_ptr()
-            c.dx = dx.data_ptr() if dx is not None else None
+            if scale is not None and ctx.needs_input_grad[1 + pin + 3 + 4 * nl]:
+                c.dscale = _acc_target(scale, rets, 4 * nl).data_ptr()
             c.save = r["save"].data_ptr()
             c.dy = dy.data_ptr()
-            c.ldo, c.lddx, c.M, c.nlayers = ldo, spec.K0, M, nl
+            c.ldo, c.M, c.nlayers = ldo, M, nl
             off = 0
             for li, L in enumerate(spec.layers):
                 N, K = L.weight.shape
@@ -391,8 +436,10 @@ class _Chains(Function):
                     d = CDw()
                     d.dy = dy.data_ptr() + 4 * off
                     if li == 0:
-                        xs = r["xsum"] if r["xsum"] is not None else r["x0v"]
-                        d.x, d.ldx = xs.data_ptr(), (spec.K0 if r["xsum"] is not None else r["ld0"])
+                        if r["xsum"] is not None:
+                            d.x, d.ldx = r["xsum"].data_ptr(), spec.K0
+                        else:
+                            d.x, d.ldx = r["x0v"].data_ptr() + 4 * r["lo"], r["ld0"]
                     else:
                         poh, poy, _ = r["offs"][li - 1]
                         d.x = r["save"].data_ptr() + 4 * (poy if spec.layers[li - 1].ln is not None else poh)
@@ -405,15 +452,13 @@ class _Chains(Function):
                     dws.append(d)
                 off += M * N
             keep.append((dy, dx, rets))
-            # gradients of this call's inputs
             if dx is not None:
                 if ctx.needs_input_grad[1 + pin]:
                     grads[1 + pin] = dx.view(r["x0_shape"])
                 if r["x1_shape"] is not None and ctx.needs_input_grad[2 + pin]:
                     grads[2 + pin] = dx.view(r["x1_shape"])
             if r["res_shape"] is not None and ctx.needs_input_grad[3 + pin]:
-                gr = g2[:, r["ocol"]:r["ocol"] + N_out] if out_slot is not None else g2
-                grads[3 + pin] = gr.reshape(r["res_shape"])
+                grads[3 + pin] = gres.reshape(r["res_shape"])
             for k, t in enumerate(rets):
                 if t is not None:
                     grads[1 + pin + 3 + k] = t
@@ -429,16 +474,20 @@ class _Chains(Function):
 def run(calls):
     """Run a group of independent chains in one forward launch (two backward launches).
 
-    ``calls``: list of ``Call``.  Returns the private outputs (calls without ``out_slot``) in call order, followed by the
-    shared output tensors in slot order.  Every input must be a CUDA fp32 tensor."""
-    flat, meta = [], []
-    slots = sorted({c.out_slot[0] for c in calls if c.out_slot is not None})
-    remap = {s: len(calls) + i for i, s in enumerate(slots)}   # shared outputs live after the private slots
+    ``calls``: list of ``Call``.  Returns the outputs of the calls without an ``out_slot`` in call order, followed by the
+    shared output tensors in order of first use.  Every input must be a CUDA fp32 tensor."""
+    flat, meta, slot_keys = [], [], []
     for c in calls:
-        flat += [c.x0, c.x1, c.residual] + c.spec.params()
-        slot = None if c.out_slot is None else (remap[c.out_slot[0]], c.out_slot[1])
-        meta.append((c.spec, slot, c.out_width))
-    return _Chains.apply((meta, len(calls) + len(slots)), *flat)
+        if c.x0_cols is not None and c.x1 is not None:
+            raise _lib.HipadError("chain: x0_cols and x1 cannot be combined")
+        params = c.spec.params()
+        if c.scale is not None:
+            params = params[:-1] + [c.scale]
+        flat += [c.x0, c.x1, c.residual] + params
+        if c.out_slot is not None and c.out_slot.key not in slot_keys:
+            slot_keys.append(c.out_slot.key)
+        meta.append((c.spec, c.out_slot, c.x0_cols))
+    return _Chains.apply((meta, slot_keys), *flat)
 
 
 def usable(x):

@@ -1,0 +1,123 @@
+// hip-ad_amd/csrc/glue.hip -- small fused kernels for the decoder's "glue": each replaces a dozen or more elementwise
+// / slice / cat launches (and their autograd mirror images) that sit between the fat kernels of a decoder layer.
+//
+//   chunk_mix_kernel       out chunk g = sum_k W[g][k] * (x0 chunk k + x1 chunk k): the query mixing of the planning
+//                          refinement head (reference models/plan/blocks.py:120-135: "aligned" = sum of the temp / spat
+//                          anchor groups' queries, speed queries = aligned + the speed groups of one interval) -- and,
+//                          with W transposed, its backward.
+//   motion_embed_kernel    class-conditioned motion-mode anchors rotated by the box yaw, last way-point, 2-D sine
+//                          embedding (reference models/sparse_onedecoder.py:428-444 get_motion_anchor +
+//                          models/attention.py:292-306 gen_sineembed_for_position): ~25 launches per decoder layer in
+//                          torch, no gradient flows through it (argmax, detached boxes, frozen anchors).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hipad.h"
+
+namespace hipad {
+
+struct MixTable {
+  float w[HIPAD_MIX_MAX][HIPAD_MIX_MAX];  // [out chunk][in chunk]
+};
+
+// x: (bs, K * rows, C), out: (bs, G * rows, C); C % 4 == 0; one float4 per thread
+__global__ __launch_bounds__(256) void chunk_mix_kernel(float *__restrict__ out, const float *__restrict__ x0,
+                                                        const float *__restrict__ x1, MixTable t, int bs, int K, int G,
+                                                        int rows, int C4) {
+  const long total = (long)bs * G * rows * C4;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c4 = (int)(idx % C4);
+  long rem = idx / C4;
+  const int r = (int)(rem % rows);
+  rem /= rows;
+  const int g = (int)(rem % G), b = (int)(rem / G);
+  const float4 *p0 = reinterpret_cast<const float4 *>(x0) + ((long)b * K * rows + r) * C4 + c4;
+  const float4 *p1 = x1 ? reinterpret_cast<const float4 *>(x1) + ((long)b * K * rows + r) * C4 + c4 : nullptr;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < K; ++k) {
+    const float w = t.w[g][k];
+    if (w != 0.f) {
+      float4 v = p0[(long)k * rows * C4];
+      if (p1) {
+        const float4 u = p1[(long)k * rows * C4];
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+      }
+      acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+    }
+  }
+  reinterpret_cast<float4 *>(out)[idx] = acc;
+}
+
+// out (bs, A, modes, 2 * half): [sin/cos interleaved embedding of y | of x] of the rotated last way-point
+//   cls (bs, A, ncls) logits, box (bs, A, D) with sin / cos yaw in columns sin_col / cos_col, table (ncls, modes, ts, 2),
+//   freq (half): 10000 ** (2 * (k // 2) / half) as torch computed it.  One thread per (b, a, mode, k).
+// Arithmetic order = the torch expression the reference evaluates (separate mul / sub kernels: no FMA contraction).
+__global__ __launch_bounds__(256) void motion_embed_kernel(float *__restrict__ out, const float *__restrict__ cls,
+                                                           const float *__restrict__ box, const float *__restrict__ table,
+                                                           const float *__restrict__ freq, long n_anchor, int ncls, int D,
+                                                           int sin_col, int cos_col, int modes, int ts, int half) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = n_anchor * modes * half;
+  if (idx >= total) return;
+  const int k = (int)(idx % half);
+  const long am = idx / half;
+  const int m = (int)(am % modes);
+  const long a = am / modes;
+  const float *cl = cls + a * ncls;
+  int best = 0;
+  float bv = cl[0];
+  for (int c = 1; c < ncls; ++c) {  // torch.argmax: first maximum; NaN counts as the maximum
+    const float v = cl[c];
+    if (v > bv || (v != v && bv == bv)) { bv = v; best = c; }
+  }
+  const float *bx = box + a * D;
+  const float yaw = atan2f(bx[sin_col], bx[cos_col]);
+  const float cy = cosf(yaw), sy = sinf(yaw);
+  const float *pt = table + (((long)best * modes + m) * ts + (ts - 1)) * 2;
+  const float x = pt[0], y = pt[1];
+  const float rx = __fsub_rn(__fmul_rn(cy, x), __fmul_rn(sy, y));
+  const float ry = __fadd_rn(__fmul_rn(sy, x), __fmul_rn(cy, y));
+  const float f = freq[k];
+  const float ay = __fdiv_rn(__fmul_rn(ry, 6.283185307179586f), f);
+  const float ax = __fdiv_rn(__fmul_rn(rx, 6.283185307179586f), f);
+  float *o = out + am * (2 * half);
+  o[k] = (k & 1) ? cosf(ay) : sinf(ay);
+  o[half + k] = (k & 1) ? cosf(ax) : sinf(ax);
+}
+
+}  // namespace hipad
+
+using namespace hipad;
+
+extern "C" {
+
+int hipad_chunk_mix(float *out, const float *x0, const float *x1, const float *weights, int bs, int in_chunks,
+                    int out_chunks, int rows, int channels, hipad_stream_t stream) {
+  if (!out || !x0 || !weights || bs <= 0 || rows <= 0 || channels <= 0 || (channels & 3)) return HIPAD_EINVAL;
+  if (in_chunks < 1 || out_chunks < 1 || in_chunks > HIPAD_MIX_MAX || out_chunks > HIPAD_MIX_MAX) return HIPAD_ERANGE;
+  if ((((uintptr_t)out | (uintptr_t)x0 | (uintptr_t)x1) & 15) != 0) return HIPAD_EINVAL;
+  MixTable t;
+  for (int g = 0; g < HIPAD_MIX_MAX; ++g)
+    for (int k = 0; k < HIPAD_MIX_MAX; ++k)
+      t.w[g][k] = (g < out_chunks && k < in_chunks) ? weights[g * in_chunks + k] : 0.f;
+  const long total = (long)bs * out_chunks * rows * (channels / 4);
+  hipLaunchKernelGGL(chunk_mix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, x0, x1,
+                     t, bs, in_chunks, out_chunks, rows, channels / 4);
+  return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
+}
+
+int hipad_motion_query_embed(float *out, const float *cls, const float *box, const float *table, const float *freq,
+                             long long n_anchor, int num_classes, int box_dim, int sin_col, int cos_col, int modes,
+                             int steps, int half_dim, hipad_stream_t stream) {
+  if (!out || !cls || !box || !table || !freq) return HIPAD_EINVAL;
+  if (n_anchor <= 0 || num_classes <= 0 || modes <= 0 || steps <= 0 || half_dim <= 0) return HIPAD_EINVAL;
+  if (sin_col < 0 || cos_col < 0 || sin_col >= box_dim || cos_col >= box_dim) return HIPAD_EINVAL;
+  const long total = (long)n_anchor * modes * half_dim;
+  if (total >= (1l << 40)) return HIPAD_ERANGE;
+  hipLaunchKernelGGL(motion_embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out,
+                     cls, box, table, freq, (long)n_anchor, num_classes, box_dim, sin_col, cos_col, modes, steps, half_dim);
+  return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
+}
+
+}  // extern "C"

@@ -399,3 +399,39 @@ class _FocalLoss(Function):
 def focal_loss(logits, target, weight=None, avg_factor=None, layers=1, alpha=0.25, gamma=2.0):
     """Per-layer sigmoid focal loss (see include/hipad.h): logits (rows, C), integer targets in [0, C] -> (layers,)."""
     return _FocalLoss.apply(logits, target, weight, avg_factor, int(layers), float(alpha), float(gamma))
+
+
+class _ChunkMix(Function):
+    @staticmethod
+    def forward(ctx, x0, x1, table, rows):
+        a = _c32(x0)
+        b = None if x1 is None else _c32(x1)
+        ctx.table, ctx.rows = table, rows
+        ctx.two = x1 is not None
+        return _lib.chunk_mix(a, b, table, rows)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        t = ctx.table
+        tt = tuple(tuple(t[g][k] for g in range(len(t))) for k in range(len(t[0])))   # transposed
+        dx = _lib.chunk_mix(_c32(gout), None, tt, ctx.rows)
+        return dx, (dx if ctx.two else None), None, None
+
+
+def chunk_mix(x0, x1, table, rows):
+    """Chunks of ``rows`` rows along dim 1: out chunk g = sum_k table[g][k] * (x0 chunk k + x1 chunk k) in ONE launch (and
+    one for the backward); see include/hipad.h.  CPU tensors: the same expression in torch ops."""
+    table = tuple(tuple(float(v) for v in row) for row in table)
+    if not x0.is_cuda:
+        x = x0 if x1 is None else x0 + x1
+        chunks = x.split(rows, dim=1)
+        outs = []
+        for row in table:
+            acc = None
+            for w, c in zip(row, chunks):
+                if w != 0.0:
+                    acc = c * w if acc is None else acc + c * w
+            outs.append(acc if acc is not None else torch.zeros_like(chunks[0]))
+        return torch.cat(outs, dim=1)
+    return _ChunkMix.apply(x0, x1, table, int(rows))

@@ -44,6 +44,8 @@ SIGNATURES = {
     "hipad_adamw_step": (c_int, [c_void_p] * 4 + [ctypes.c_longlong] * 2 + [ctypes.c_float] * 7
                          + [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p]),
     "hipad_lr_factor": (ctypes.c_float, [c_void_p, c_int]),
+    "hipad_chunk_mix": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "hipad_motion_query_embed": (c_int, [c_void_p] * 5 + [ctypes.c_longlong] + [c_int] * 7 + [c_void_p]),
     "hipad_chain_forward": (c_int, [c_void_p, c_int, c_void_p]),
     "hipad_chain_debug_stamps": (None, [c_void_p]),
     "hipad_chain_backward_dx": (c_int, [c_void_p, c_int, c_void_p]),
@@ -524,3 +526,41 @@ def focal_loss_forward(logits, target, weight, avg_factor, layers, alpha, gamma)
                                           stream_ptr(logits.device))
     check(st, "hipad_focal_loss_forward")
     return loss, grad
+
+
+def chunk_mix(x0, x1, table, rows):
+    """out chunk g = sum_k table[g][k] * (x0 chunk k + x1 chunk k); x: (bs, K * rows, C) -> (bs, G * rows, C).
+    ``table``: G x K nested list / tuple of floats (host)."""
+    lib = load()
+    _req(x0, torch.float32, "x0")
+    if x1 is not None:
+        _req(x1, torch.float32, "x1")
+        if x1.shape != x0.shape:
+            raise HipadError("chunk_mix: x0 / x1 shapes differ")
+    G, K = len(table), len(table[0])
+    bs, n, C = x0.shape
+    if n != K * rows:
+        raise HipadError(f"chunk_mix: {n} rows != {K} chunks x {rows}")
+    out = torch.empty(bs, G * rows, C, dtype=torch.float32, device=x0.device)
+    flat = (ctypes.c_float * (G * K))(*[float(v) for row in table for v in row])
+    with torch.cuda.device(x0.device):
+        check(lib.hipad_chunk_mix(out.data_ptr(), x0.data_ptr(), _ptr(x1), flat, bs, K, G, rows, C, stream_ptr(x0.device)),
+              "hipad_chunk_mix")
+    return out
+
+
+def motion_query_embed(cls, box, table, freq, sin_col, cos_col):
+    """(bs, A, ncls) logits, (bs, A, D) boxes, (ncls, modes, ts, 2) anchors, (half,) frequencies -> (bs, A, modes, 2*half)."""
+    lib = load()
+    for t, n in ((cls, "cls"), (box, "box"), (table, "table"), (freq, "freq")):
+        _req(t, torch.float32, n)
+    bs, A, ncls = cls.shape
+    D = box.shape[-1]
+    modes, ts = table.shape[1], table.shape[2]
+    half = freq.numel()
+    out = torch.empty(bs, A, modes, 2 * half, dtype=torch.float32, device=cls.device)
+    with torch.cuda.device(cls.device):
+        check(lib.hipad_motion_query_embed(out.data_ptr(), cls.data_ptr(), box.data_ptr(), table.data_ptr(), freq.data_ptr(),
+                                           bs * A, ncls, D, sin_col, cos_col, modes, ts, half, stream_ptr(cls.device)),
+              "hipad_motion_query_embed")
+    return out

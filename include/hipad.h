@@ -408,6 +408,28 @@ int hipad_pack_weights(unsigned short *const *dst, unsigned short *const *dst_t,
                        const int *rows, const int *cols, const int *tile_start, int n_mats, int total_tiles,
                        hipad_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Decoder glue (hip-ad_amd/csrc/glue.hip).
+ * hipad_chunk_mix.  Replaces: the query mixing of the planning refinement head (reference
+ *   models/plan/blocks.py:120-135 -- "aligned" = sum of the temp / spat anchor groups' queries, each speed query =
+ *   aligned + the speed groups of its interval; ~12 slice / add / cat launches forward, ~25 backward).
+ *   x0, x1 (x1 may be NULL): (bs, in_chunks * rows, channels); out: (bs, out_chunks * rows, channels);
+ *   out chunk g = sum_k weights[g * in_chunks + k] * (x0 chunk k + x1 chunk k); weights on the HOST (<= 16 x 16).
+ *   The backward is the same call with the transposed table on the output gradient.  channels % 4 == 0.
+ * hipad_motion_query_embed.  Replaces: get_motion_anchor (reference models/sparse_onedecoder.py:428-444: anchors of the
+ *   arg-max class rotated by the box yaw) + the last way-point's gen_sineembed_for_position
+ *   (models/attention.py:292-306), ~25 elementwise launches per decoder layer; no gradient flows through it.
+ *   cls (n_anchor, num_classes) logits; box (n_anchor, box_dim); table (num_classes, modes, steps, 2);
+ *   freq (half_dim) = 10000 ** (2 * (k / 2) / half_dim); out (n_anchor, modes, 2 * half_dim) = [embed(y) | embed(x)],
+ *   embed(v)[k] = sin or cos (k odd) of v * 2 pi / freq[k], same operation order as the torch expression.
+ * ---------------------------------------------------------------------------------- */
+#define HIPAD_MIX_MAX 16
+int hipad_chunk_mix(float *out, const float *x0, const float *x1, const float *weights, int bs, int in_chunks,
+                    int out_chunks, int rows, int channels, hipad_stream_t stream);
+int hipad_motion_query_embed(float *out, const float *cls, const float *box, const float *table, const float *freq,
+                             long long n_anchor, int num_classes, int box_dim, int sin_col, int cos_col, int modes,
+                             int steps, int half_dim, hipad_stream_t stream);
+
 /* Tuning knob (host side, process-wide): target number of (point, camera) pairs one
  * wavefront owns in the forward / backward kernels.  <=0 restores the default. */
 void hipad_daf_set_pairs_per_wave(int fwd, int bwd);

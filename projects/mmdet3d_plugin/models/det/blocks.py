@@ -62,8 +62,10 @@ class SparseBox3DEncoder(BaseModule):
             return None
         total = sum(sp.N_out for sp in specs)
         calls, col = [], 0
+        shape = tuple(box_3d.shape[:-1]) + (total,)
         for sp, (_, lo, hi) in zip(specs, fcs):
-            calls.append(CH.Call(sp, box_3d[..., lo:hi], out_slot=(0, col), out_width=total))
+            # columns lo..hi of the anchors in, columns col.. of the embedding out: no slice / cat kernels either way
+            calls.append(CH.Call(sp, box_3d, x0_cols=(lo, hi), out_slot=CH.OutSlot("embed", shape, col0=col)))
             col += sp.N_out
         (out,) = CH.run(calls)
         return out if self.output_fc is None else self.output_fc(out)
@@ -93,18 +95,42 @@ class SparseBox3DRefinementModule(BaseModule):
         if self.with_cls_branch:
             nn.init.constant_(self.cls_layers[-1].bias, bias_init_with_prob(0.01))
 
+    def _fused_update(self, bs, time_interval, like):
+        """Per-column factor c with output = delta * c + anchor when the refinement is a pure column-wise affine update
+        of the anchor: all state columns refined residually (refine_yaw), no yaw normalisation, one sample (one frame
+        interval for every row).  None otherwise."""
+        n_state = len(self.refine_state)
+        if self.normalize_yaw or n_state != VX or bs != 1:
+            return None
+        if self.output_dim <= 8:
+            return like.new_ones(self.output_dim)
+        if not isinstance(time_interval, torch.Tensor):
+            time_interval = like.new_tensor(time_interval)
+        inv_dt = (1.0 / time_interval.reshape(-1)[:1].to(like.dtype)).expand(self.output_dim - VX)
+        return torch.cat([like.new_ones(VX), inv_dt])
+
     def forward(self, instance_feature, anchor, anchor_embed, time_interval=1.0, return_cls=True):
         from hipad_amd import chain as CH
         cls = quality = grouped = None
+        fused = False
+        if return_cls and not self.with_cls_branch:
+            raise AssertionError("Without classification layers !!!")
         if CH.usable(instance_feature):
             # the regression, class and quality stacks as ONE chain launch (the input sum inside the kernel)
             specs = [CH.spec_of(self.layers)]
-            if return_cls and self.with_cls_branch:
+            if return_cls:
                 specs.append(CH.spec_of(self.cls_layers))
                 if self.with_quality_estimation:
                     specs.append(CH.spec_of(self.quality_layers))
             if all(sp is not None for sp in specs):
-                calls = [CH.Call(specs[0], instance_feature, anchor_embed)]
+                col = self._fused_update(instance_feature.shape[0], time_interval, instance_feature)
+                if col is not None and specs[0].scale is not None:
+                    # output = delta * c + anchor with delta = stack(...) * Scale: fold c into the scale, the anchor in as
+                    # the residual -- the slice / add / divide / cat kernels of the update (and their backward) vanish
+                    fused = True
+                    calls = [CH.Call(specs[0], instance_feature, anchor_embed, residual=anchor, scale=specs[0].scale * col)]
+                else:
+                    calls = [CH.Call(specs[0], instance_feature, anchor_embed)]
                 if len(specs) > 1:
                     calls.append(CH.Call(specs[1], instance_feature))
                 if len(specs) > 2:
@@ -114,6 +140,8 @@ class SparseBox3DRefinementModule(BaseModule):
             delta = grouped[0]
             cls = grouped[1] if len(grouped) > 1 else None
             quality = grouped[2] if len(grouped) > 2 else None
+            if fused:
+                return delta, cls, quality
         else:
             feature = instance_feature + anchor_embed
             delta = self.layers(feature)
@@ -134,13 +162,9 @@ class SparseBox3DRefinementModule(BaseModule):
             pieces.append(delta[..., VX:] / dt + anchor[..., VX:])
         output = torch.cat(pieces, dim=-1)
         if return_cls and grouped is None:
-            if not self.with_cls_branch:
-                raise AssertionError("Without classification layers !!!")
             cls = self.cls_layers(instance_feature)
             if self.with_quality_estimation:
                 quality = self.quality_layers(feature)
-        elif return_cls and not self.with_cls_branch:
-            raise AssertionError("Without classification layers !!!")
         return output, cls, quality
 
 

@@ -78,48 +78,87 @@ class SparsePlanAlignRefinementModule(BaseModule):
         if hasattr(self, "plan_cls_branch_speed"):
             nn.init.constant_(self.plan_cls_branch_speed[-1].bias, prior)
 
-    def _forward_chains(self, aligned, speed_sources, areas, anchor):
-        """GPU path: every distinct (branch, input) pair of the module as one chain of ONE grouped launch (eight chains
-        for the ten anchor types of the HiP-AD configs) instead of ~50 Linear / LayerNorm launches on 48..144 rows."""
+    def _forward_chains(self, aligned, speed_in, areas, anchor):
+        """Every distinct (branch, input) pair of the module as one chain of ONE grouped launch (eight chains for the ten
+        anchor types of the HiP-AD configs) instead of ~50 Linear / LayerNorm launches on 48..144 rows.  With batch 1
+        the regression chains write their rows of the stacked (1, groups * modes, 2 * ts) result directly."""
         from hipad_amd import chain as CH
-        speed_in = torch.cat(speed_sources, dim=1) if len(speed_sources) > 1 else (speed_sources[0] if speed_sources else None)
-        calls, index = [], {}
-
-        def add(module, key, x):
-            k = (id(module), key)
-            if k not in index:
-                spec = CH.spec_of(module)
-                if spec is None:
-                    return False
-                index[k] = len(calls)
-                calls.append(CH.Call(spec, x))
-            return True
-
-        plan = []
-        for t in self.anchor_types:
+        bs, rows = aligned.shape[:2]
+        n_area = max(1, len(areas))
+        stacked = bs == 1   # rows of one group are contiguous in the stacked tensor only for a single sample
+        plan, reg_calls, cls_calls = [], {}, {}
+        for i, t in enumerate(self.anchor_types):
             branch = getattr(self, f"plan_reg_branch_{t[0]}_{t[1]}")
             if t[0] in ("temp", "spat"):
-                ok = add(branch, "aligned", aligned) and add(self.plan_cls_branch, "aligned", aligned)
-                plan.append(((id(branch), "aligned"), (id(self.plan_cls_branch), "aligned"), None))
+                rk, ck, piece, x, cls_mod = (id(branch), "aligned"), (id(self.plan_cls_branch), "aligned"), None, aligned, self.plan_cls_branch
             elif t[0] == "speed":
-                ok = add(branch, "speed", speed_in) and add(self.plan_cls_branch_speed, "speed", speed_in)
-                plan.append(((id(branch), "speed"), (id(self.plan_cls_branch_speed), "speed"), areas.index(t[2])))
+                rk, ck, piece, x, cls_mod = (id(branch), "speed"), (id(self.plan_cls_branch_speed), "speed"), areas.index(t[2]), speed_in, self.plan_cls_branch_speed
             else:
                 raise NotImplementedError(t[0])
-            if not ok:
+            reg_calls.setdefault(rk, dict(module=branch, x=x, first=i, members=[]))["members"].append((i, piece))
+            cls_calls.setdefault(ck, dict(module=cls_mod, x=x))
+            plan.append((rk, ck, piece))
+        # a regression chain may write straight into the stacked result when its pieces are consecutive anchor groups
+        for c in reg_calls.values():
+            idx = [i for i, _ in c["members"]]
+            pcs = [p for _, p in c["members"]]
+            c["direct"] = stacked and (pcs == [None] or (pcs == list(range(n_area)) and idx == list(range(idx[0], idx[0] + n_area))))
+        all_direct = all(c["direct"] for c in reg_calls.values())
+        if not all_direct:  # mixed placement is not produced by any config: all or nothing keeps the code simple
+            for c in reg_calls.values():
+                c["direct"] = False
+        calls, order = [], []
+        for key, c in list(reg_calls.items()) + list(cls_calls.items()):
+            spec = CH.spec_of(c["module"])
+            if spec is None:
                 return None
-        outs = CH.run(calls)
-        regs, scores = [], []
-        n_area = max(1, len(areas))
-        for rk, sk, area in plan:
-            r, sc = outs[index[rk]], outs[index[sk]]
-            if area is not None:
-                r, sc = r.chunk(n_area, dim=1)[area], sc.chunk(n_area, dim=1)[area]
-            regs.append(r)
-            scores.append(sc)
-        return torch.cat(regs, dim=1) + anchor, torch.cat(scores, dim=1)
+            slot = None
+            if c.get("direct"):
+                slot = CH.OutSlot("reg", (1, rows * len(self.anchor_types), spec.N_out), row0=c["first"] * rows)
+            calls.append(CH.Call(spec, c["x"], out_slot=slot))
+            order.append((key, slot is not None))
+        outs = list(CH.run(calls))
+        private = {key: None for key, direct in order if not direct}
+        it = iter(outs)
+        for key in private:
+            private[key] = next(it)
+        pieces_of = {key: (t.split(rows, dim=1) if t.shape[1] != rows else (t,)) for key, t in private.items()}
+        if all_direct:
+            regs = outs[-1]
+        else:
+            regs = torch.cat([pieces_of[rk][0 if piece is None else piece] for rk, _, piece in plan], dim=1)
+        scores = torch.cat([pieces_of[ck][0 if piece is None else piece] for _, ck, piece in plan], dim=1)
+        return regs + anchor, scores
+
+    def _mix_table(self):
+        """Rows = [aligned] + one speed query per interval, columns = anchor groups: which group queries each sums."""
+        areas = list(getattr(self, "speed_areas", []))
+        aligned = [1.0 if t[0] in ("temp", "spat") else 0.0 for t in self.anchor_types]
+        table = [aligned]
+        for area in areas:
+            table.append([a + (1.0 if (t[0] == "speed" and t[2] == area) else 0.0) for a, t in zip(aligned, self.anchor_types)])
+        return table, areas
 
     def forward(self, instance_feature, anchor, anchor_embed, use_plan_anchor_embed=True):
+        from hipad_amd import chain as CH
+        from hipad_amd import functional as HF
+        if CH.usable(instance_feature) and instance_feature.shape[1] % self.anchor_group == 0 \
+                and instance_feature.shape[-1] % 4 == 0:
+            # GPU path: the group mixing in one launch, then every distinct (branch, input) pair as one chain of ONE
+            # grouped launch
+            table, areas = self._mix_table()
+            rows = instance_feature.shape[1] // self.anchor_group
+            mixed = HF.chunk_mix(instance_feature, anchor_embed if use_plan_anchor_embed else None, table, rows)
+            if areas:
+                aligned, speed_in = mixed.split([rows, rows * len(areas)], dim=1)
+            else:
+                aligned, speed_in = mixed, None
+            out = self._forward_chains(aligned, speed_in, areas, anchor)
+            if out is not None:
+                return out
+        return self._forward_layers(instance_feature, anchor, anchor_embed, use_plan_anchor_embed)
+
+    def _forward_layers(self, instance_feature, anchor, anchor_embed, use_plan_anchor_embed=True):
         if use_plan_anchor_embed:
             instance_feature = instance_feature + anchor_embed
         chunks = instance_feature.chunk(self.anchor_group, dim=1)
@@ -134,11 +173,6 @@ class SparsePlanAlignRefinementModule(BaseModule):
         # of the speed groups that share an interval).  Evaluate every distinct (module, input) once and
         # stack the inputs of a shared module into one call.
         areas = list(speed_query)
-        from hipad_amd import chain as CH
-        if CH.usable(instance_feature):
-            out = self._forward_chains(aligned, [speed_query[a] for a in areas], areas, anchor)
-            if out is not None:
-                return out
         cache = {}
 
         def run(module, key, sources):

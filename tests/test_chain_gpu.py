@@ -150,7 +150,7 @@ def test_group_of_chains_writes_one_concatenated_tensor():
     col = 0
     calls = []
     for m, w, (lo, hi) in zip(mods, widths, cols):
-        calls.append(CH.Call(CH.spec_of(m), a1[..., lo:hi], out_slot=(0, col), out_width=256))
+        calls.append(CH.Call(CH.spec_of(m), a1, x0_cols=(lo, hi), out_slot=CH.OutSlot("cat", (2, 450, 256), col0=col)))
         col += w
     (out,) = CH.run(calls)
     assert out.shape == (2, 450, 256)
@@ -200,3 +200,75 @@ def test_unsupported_stacks_fall_back_to_layers():
     assert CH.spec_of(wide) is None
     y = wide(torch.randn(4, 256).cuda())
     assert y.shape == (4, 256)
+
+
+def test_row_slots_scale_override_and_shared_parent_gradient():
+    """Two chains stack their rows into one tensor (OutSlot.row0); a call-level scale replaces the stack's Scale and
+    receives a gradient; chains reading column ranges of one parent return ONE gradient tensor for it."""
+    from hipad_amd import chain as CH
+    from hipad_amd import functional as HF
+    g = torch.Generator().manual_seed(21)
+    m1, m2 = build("reg", 256, out_dim=12), build("reg", 256, out_dim=12)
+    for m in (m1, m2):
+        for p in m.parameters():
+            p.grad = torch.zeros_like(p)
+    x1 = torch.randn(1, 48, 256, generator=g).cuda().requires_grad_(True)
+    x2 = torch.randn(1, 144, 256, generator=g).cuda().requires_grad_(True)
+    col = torch.linspace(0.5, 2.0, 12).cuda()
+    s2 = (m2[-1].scale * col)
+    go = torch.randn(1, 192, 12, generator=g).cuda()
+    (out,) = CH.run([CH.Call(CH.spec_of(m1), x1, out_slot=CH.OutSlot("o", (1, 192, 12), row0=0)),
+                     CH.Call(CH.spec_of(m2), x2, out_slot=CH.OutSlot("o", (1, 192, 12), row0=48), scale=s2)])
+    out.backward(go)
+    got = (out.detach(), x1.grad.clone(), x2.grad.clone(), m2[-1].scale.grad.clone(), m1[-1].scale.grad.clone())
+    r1, r2 = copy.deepcopy(m1), copy.deepcopy(m2)
+    for m in (r1, r2):
+        for p in m.parameters():
+            p.grad = torch.zeros_like(p)
+    y1, y2 = x1.detach().clone().requires_grad_(True), x2.detach().clone().requires_grad_(True)
+    HF.USE_CHAINS = False
+    try:
+        a = r1(y1)
+        b = r2[:-1](y2) * (r2[-1].scale * col)
+    finally:
+        HF.USE_CHAINS = True
+    ref = torch.cat([a, b], dim=1)
+    ref.backward(go)
+    assert fro(got[0], ref) < 2e-3
+    assert fro(got[1], y1.grad) < 6e-3 and fro(got[2], y2.grad) < 6e-3
+    assert fro(got[3], r2[-1].scale.grad) < 6e-3 and fro(got[4], r1[-1].scale.grad) < 6e-3
+
+
+def test_chunk_mix_and_motion_embedding_match_torch():
+    from hipad_amd import functional as HF
+    from hipad_amd import lib
+    from projects.mmdet3d_plugin.models.attention import gen_sineembed_for_position
+    g = torch.Generator().manual_seed(8)
+    x0 = torch.randn(2, 480, 256, generator=g).cuda().requires_grad_(True)
+    x1 = torch.randn(2, 480, 256, generator=g).cuda().requires_grad_(True)
+    table = [[1, 1, 1, 1, 0, 0, 0, 0, 0, 0], [1, 1, 1, 1, 1, 0, 0, 1, 0, 0], [1, 1, 1, 1, 0, 1, 0, 0, 1, 0],
+             [1, 1, 1, 1, 0, 0, 1, 0, 0, 1]]
+    out = HF.chunk_mix(x0, x1, table, 48)
+    go = torch.randn(out.shape, generator=g).cuda()
+    out.backward(go)
+    y0, y1 = x0.detach().cpu().requires_grad_(True), x1.detach().cpu().requires_grad_(True)
+    ref = HF.chunk_mix(y0, y1, table, 48)       # the torch expression (CPU branch)
+    ref.backward(go.cpu())
+    assert float((out.cpu() - ref).abs().max()) < 1e-5
+    assert float((x0.grad.cpu() - y0.grad).abs().max()) < 1e-5 and torch.equal(x0.grad, x1.grad)
+    # motion-mode embedding vs the torch expression of the reference
+    cls = torch.randn(1, 900, 9, generator=g).cuda()
+    box = torch.randn(1, 900, 11, generator=g).cuda()
+    anchors = (torch.randn(9, 6, 6, 2, generator=g) * 20).cuda()
+    idx = torch.arange(128, dtype=torch.float32).cuda()
+    freq = 10000 ** (2 * torch.div(idx, 2, rounding_mode="floor") / 128)
+    got = lib.motion_query_embed(cls, box, anchors, freq, 6, 7)
+    modes = anchors[cls.argmax(dim=-1)]
+    yaw = torch.atan2(box[..., 6], box[..., 7])
+    c, s = yaw.cos()[..., None, None], yaw.sin()[..., None, None]
+    x, y = modes[..., 0], modes[..., 1]
+    pts = torch.stack([c * x - s * y, s * x + c * y], dim=-1)
+    want = gen_sineembed_for_position(pts[..., -1, :])
+    assert got.shape == want.shape
+    # sin / cos of arguments up to ~1e3 rad: a last-bit difference in the argument moves the value by ~1e-4
+    assert float((got - want).abs().max()) < 2e-3 and float((got - want).abs().mean()) < 1e-5
