@@ -275,6 +275,21 @@ def force_fp32(*dargs, **dkw):
 auto_fp16 = force_fp32
 
 
+def _identity_choice(tag, choice):
+    return choice
+
+
+# Every data-dependent DISCRETE choice of the path (temporal top-k selections, the motion-mode anchors' class, Hungarian
+# indices, point order of a matched poly-line, winning trajectory mode, class-score gate on regression positives) passes
+# through ``discrete_choice[0](tag, index_tensor)``.  Identity in the product; parity tests swap in a recorder / replayer
+# so that two numerically different runs are compared on the same choices instead of on near-ties that fell the other way.
+discrete_choice = [_identity_choice]
+
+
+def discrete(tag, choice):
+    return discrete_choice[0](tag, choice)
+
+
 def reduce_mean(tensor):
     """All-reduce(mean) across ranks when torch.distributed is initialised (mmdet.core.reduce_mean)."""
     import torch.distributed as dist

@@ -141,10 +141,14 @@ __device__ __forceinline__ float4 ch_ld4(const float *__restrict__ p, int c0, in
   return make_float4(c0 + 0 < n ? a : 0.f, c0 + 1 < n ? b : 0.f, c0 + 2 < n ? c : 0.f, c0 + 3 < n ? d : 0.f);
 }
 
-// acc[tt][i] = A(LDS operand tile, rows 16 i ..) x B(bw[tt]) for the wave's tiles
-template <int R, bool FULL>
+// acc[tt][i] = A(LDS operand tile, rows 16 i ..) x B(bw[tt]) for the wave's tiles.  SPLIT: the activations are held as
+// hi + lo bf16 pairs (lo = bf16(v - hi)) and multiplied in two MFMAs against the same weight fragment: the activation
+// side of the product is then exact to ~2^-17, only the weights carry bf16 rounding -- the forward's error drops by
+// ~1/sqrt(2) for one extra MFMA per fragment (the MFMA phase is ~10 % of a layer; no extra weight traffic).
+template <int R, bool FULL, bool SPLIT>
 __device__ __forceinline__ void ch_mma(f32x4 (&acc)[CH_MAXT][R / 16], const bf16x8 (&bw)[CH_MAXT][CH_MAXS],
-                                       const short (*X)[CH_XS], int rows, int depth, int wv, int l15, int quad) {
+                                       const short (*X)[CH_XS], const short (*XL)[CH_XS], int rows, int depth, int wv,
+                                       int l15, int quad) {
 #pragma unroll
   for (int tt = 0; tt < CH_MAXT; ++tt)
 #pragma unroll
@@ -158,6 +162,12 @@ __device__ __forceinline__ void ch_mma(f32x4 (&acc)[CH_MAXT][R / 16], const bf16
 #pragma unroll
         for (int tt = 0; tt < CH_MAXT; ++tt)
           acc[tt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bw[tt][s], acc[tt][i], 0, 0, 0);
+        if (SPLIT) {
+          const bf16x8 al = *reinterpret_cast<const bf16x8 *>(&XL[16 * i + l15][32 * s + 8 * quad]);
+#pragma unroll
+          for (int tt = 0; tt < CH_MAXT; ++tt)
+            acc[tt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bw[tt][s], acc[tt][i], 0, 0, 0);
+        }
       }
     return;
   }
@@ -172,6 +182,10 @@ __device__ __forceinline__ void ch_mma(f32x4 (&acc)[CH_MAXT][R / 16], const bf16
           for (int i = 0; i < R / 16; ++i) {
             const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&X[16 * i + l15][32 * s + 8 * quad]);
             acc[tt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bw[tt][s], acc[tt][i], 0, 0, 0);
+            if (SPLIT) {
+              const bf16x8 al = *reinterpret_cast<const bf16x8 *>(&XL[16 * i + l15][32 * s + 8 * quad]);
+              acc[tt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bw[tt][s], acc[tt][i], 0, 0, 0);
+            }
           }
         }
       }
@@ -185,11 +199,21 @@ __device__ __forceinline__ void ch_fetch_any(bf16x8 (&bw)[CH_MAXT][CH_MAXS], con
   if (rows == CH_W && depth == CH_W) ch_fetch<true>(bw, w, rows, depth, wv, lane);
   else ch_fetch<false>(bw, w, rows, depth, wv, lane);
 }
-template <int R>
+template <int R, bool SPLIT>
 __device__ __forceinline__ void ch_mma_any(f32x4 (&acc)[CH_MAXT][R / 16], const bf16x8 (&bw)[CH_MAXT][CH_MAXS],
-                                           const short (*X)[CH_XS], int rows, int depth, int wv, int l15, int quad) {
-  if (rows == CH_W && depth == CH_W) ch_mma<R, true>(acc, bw, X, rows, depth, wv, l15, quad);
-  else ch_mma<R, false>(acc, bw, X, rows, depth, wv, l15, quad);
+                                           const short (*X)[CH_XS], const short (*XL)[CH_XS], int rows, int depth, int wv,
+                                           int l15, int quad) {
+  if (rows == CH_W && depth == CH_W) ch_mma<R, true, SPLIT>(acc, bw, X, XL, rows, depth, wv, l15, quad);
+  else ch_mma<R, false, SPLIT>(acc, bw, X, XL, rows, depth, wv, l15, quad);
+}
+
+// hi / lo bf16 halves of four activations into the two operand tiles
+__device__ __forceinline__ void ch_store_split(short *hi, short *lo, float4 v) {
+  const __bf16 h0 = (__bf16)v.x, h1 = (__bf16)v.y, h2 = (__bf16)v.z, h3 = (__bf16)v.w;
+  *reinterpret_cast<short4 *>(hi) = make_short4(__builtin_bit_cast(short, h0), __builtin_bit_cast(short, h1),
+                                                __builtin_bit_cast(short, h2), __builtin_bit_cast(short, h3));
+  *reinterpret_cast<short4 *>(lo) = make_short4(ch_bf16(v.x - (float)h0), ch_bf16(v.y - (float)h1), ch_bf16(v.z - (float)h2),
+                                                ch_bf16(v.w - (float)h3));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -197,7 +221,8 @@ __device__ __forceinline__ void ch_mma_any(f32x4 (&acc)[CH_MAXT][R / 16], const 
 // ---------------------------------------------------------------------------------------------------------------
 template <int R>
 __global__ __launch_bounds__(256) void chain_fwd_kernel(const ChainFwdArgs a) {
-  __shared__ short X[R][CH_XS];
+  __shared__ short X[R][CH_XS];    // activations, bf16 hi halves (MFMA A operand)
+  __shared__ short XL[R][CH_XS];   // ... lo halves
   __shared__ float Y[R][CH_YS];
   __shared__ ChainFwd desc;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, quad = lane >> 4;
@@ -248,7 +273,7 @@ __global__ __launch_bounds__(256) void chain_fwd_kernel(const ChainFwdArgs a) {
           float4 v = make_float4(v0[it].x + v1[it].x, v0[it].y + v1[it].y, v0[it].z + v1[it].z, v0[it].w + v1[it].w);
           if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
           if (xs && x1 && ok) *reinterpret_cast<float4 *>(xs + (size_t)row * K0 + col) = v;
-          *reinterpret_cast<short4 *>(&X[r][col]) = make_short4(ch_bf16(v.x), ch_bf16(v.y), ch_bf16(v.z), ch_bf16(v.w));
+          ch_store_split(&X[r][col], &XL[r][col], v);
         }
       }
     } else {
@@ -262,7 +287,9 @@ __global__ __launch_bounds__(256) void chain_fwd_kernel(const ChainFwdArgs a) {
             if (xs) xs[(size_t)row * K0 + col] = v;
           }
         }
-        X[r][col] = ch_bf16(v);
+        const __bf16 hi = (__bf16)v;
+        X[r][col] = __builtin_bit_cast(short, hi);
+        XL[r][col] = ch_bf16(v - (float)hi);
       }
       ch_fetch_any(bw, c.L[0].w, c.L[0].N, c.L[0].K, wv, lane);
     }
@@ -294,7 +321,7 @@ __global__ __launch_bounds__(256) void chain_fwd_kernel(const ChainFwdArgs a) {
     __syncthreads();  // operand tile complete
     CH_STAMP();
     f32x4 acc[CH_MAXT][R / 16];
-    ch_mma_any<R>(acc, bw, X, N, K, wv, l15, quad);
+    ch_mma_any<R, true>(acc, bw, X, XL, N, K, wv, l15, quad);
     CH_STAMP();
     // bias (+ ReLU) -> fp32 result tile; element (i, r): row 16 i + 4 quad + r, column 16 t + l15
 #pragma unroll
@@ -376,8 +403,8 @@ __global__ __launch_bounds__(256) void chain_fwd_kernel(const ChainFwdArgs a) {
         }
       }
       if (!last) {
-        if (c0 < Np)  // next layer's operand tile, zero-padded to a multiple of 32 columns
-          *reinterpret_cast<short4 *>(&X[r][c0]) = make_short4(ch_bf16(v.x), ch_bf16(v.y), ch_bf16(v.z), ch_bf16(v.w));
+        if (c0 < Np)  // next layer's operand tiles, zero-padded to a multiple of 32 columns
+          ch_store_split(&X[r][c0], &XL[r][c0], v);
       } else if (rok && c0 < N) {
         float4 o = make_float4(v.x * sc.x, v.y * sc.y, v.z * sc.z, v.w * sc.w);
         if (c.residual) {
@@ -557,7 +584,7 @@ __global__ __launch_bounds__(256) void chain_bwd_kernel(const ChainBwdArgs a) {
     if (need_dx) {
       // dX[r][k] = sum_n dY[r][n] Wt[k][n]: output columns k < K, reduction over n < N
       f32x4 acc[CH_MAXT][R / 16];
-      ch_mma_any<R>(acc, bw, X, K, N, wv, l15, quad);
+      ch_mma_any<R, false>(acc, bw, X, X, K, N, wv, l15, quad);
       const int ktiles = (K + 15) >> 4;
 #pragma unroll
       for (int tt = 0; tt < CH_MAXT; ++tt) {

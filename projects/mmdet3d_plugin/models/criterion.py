@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from hipad_amd.compat import BBOX_SAMPLERS, LOSSES, build_from_cfg, reduce_mean
+from hipad_amd.compat import BBOX_SAMPLERS, LOSSES, build_from_cfg, discrete, reduce_mean
 from projects.mmdet3d_plugin.core.box3d import CNS, COS_YAW, SIN_YAW, YNS
 
 __all__ = ["FocalLoss", "L1Loss", "CrossEntropyLoss", "GaussianFocalLoss", "SparseBox3DLoss", "LinesL1Loss",
@@ -265,7 +265,7 @@ class SparseBox3DTarget:
                         * _const(self.reg_weights, box_pred)).sum(-1) * self.box_weight
             cost = cls_cost + box_cost
             cost = torch.where(torch.isneginf(cost) | torch.isnan(cost), 1e8, cost)
-            index = linear_assignment(cost.transpose(1, 2).contiguous(), count)
+            index = discrete("assign.det", linear_assignment(cost.transpose(1, 2).contiguous(), count))
         index = torch.where(valid, index, torch.full_like(index, -1))
         self.indices = index
         cls_target = _scatter_rows(num_pred, index, labels, fill=num_cls)
@@ -303,7 +303,8 @@ class SparsePoint3DTarget:
             dist = _smooth_l1(diff, self.reg_cost_beta).sum(-1) / (pts_pred.shape[-1] // 2)
             reg_cost, perm = dist.min(dim=-1)                                         # (bs, P, G)
             cost = torch.nan_to_num(cls_cost + reg_cost * self.reg_cost_weight)
-            index = linear_assignment(cost.transpose(1, 2).contiguous(), count)
+            index = discrete("assign.map", linear_assignment(cost.transpose(1, 2).contiguous(), count))
+            perm = discrete("line_order", perm)
         index = torch.where(valid, index, torch.full_like(index, -1))
         # point order of ground-truth line g as seen from its matched prediction
         best = torch.gather(perm.transpose(1, 2), 2, index.clamp(min=0)[..., None]).squeeze(-1)   # (bs, G)
@@ -317,7 +318,7 @@ def _closest_mode(reg_pred, reg_target, reg_weight):
     """(bs, N, modes, ts, 2) offsets vs (bs, N, ts, 2): index of the mode whose cumulative trajectory is closest
     (mean masked L2), reference motion/target.py:5-19 = plan/target.py:7-21."""
     dist = torch.linalg.norm(reg_target.cumsum(dim=-2).unsqueeze(2) - reg_pred.cumsum(dim=-2), dim=-1)
-    return (dist * reg_weight.unsqueeze(2)).mean(dim=-1).argmin(dim=-1)
+    return discrete("mode", (dist * reg_weight.unsqueeze(2)).mean(dim=-1).argmin(dim=-1))
 
 
 def _take_mode(reg_pred, mode_idx):
@@ -464,7 +465,7 @@ class DecoderLoss:
         num_pos = torch.clamp(reduce_mean(matched.reshape(layers, -1).sum(dim=1).to(torch.float32)), min=1.0)   # (L,)
         rows = matched
         if self.cls_threshold_to_reg > 0:
-            rows = rows & (cls.max(dim=-1).values.sigmoid() > self.cls_threshold_to_reg)
+            rows = rows & discrete("cls_gate", cls.max(dim=-1).values.sigmoid() > self.cls_threshold_to_reg)
         cls_loss = loss_cls(cls.flatten(end_dim=1), cls_target.flatten(end_dim=1), avg_factor=num_pos, layers=layers)
         weights = (weights * _const(reg_weights, reg)).flatten(end_dim=1)
         reg_target = reg_target.flatten(end_dim=1)

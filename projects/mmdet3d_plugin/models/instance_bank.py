@@ -10,7 +10,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from hipad_amd.compat import PLUGIN_LAYERS, build_from_cfg
+from hipad_amd.compat import PLUGIN_LAYERS, build_from_cfg, discrete
 from projects.mmdet3d_plugin.core.box3d import VX
 
 __all__ = ["InstanceBank", "select_topk", "ego_motion_between"]
@@ -19,6 +19,9 @@ __all__ = ["InstanceBank", "select_topk", "ego_motion_between"]
 def select_topk(confidence, k, *tensors):
     """Top-k along dim 1 of ``confidence`` (bs, N); gathers the same rows from each (bs, N, ...) tensor."""
     conf, idx = torch.topk(confidence, k, dim=1)
+    forced = discrete("topk", idx)
+    if forced is not idx:  # a parity test replays another run's selection
+        idx, conf = forced, torch.gather(confidence, 1, forced)
     picked = []
     for t in tensors:
         flat = t.reshape(t.shape[0], t.shape[1], -1)

@@ -68,23 +68,24 @@ def run_three_ways(mod, inputs, gout_seed=1, x1=None, residual=None):
     return res
 
 
-def check(res, tight=2e-3, loose=2e-2):
-    """chain vs the per-layer HIP kernels: tight (same operand rounding, different summation order).  chain vs torch fp32:
-    the output within `loose`; gradients no further from torch than the per-layer kernels are (x1.5 + 1e-2): through five
-    bf16 layers with ReLU gates and LayerNorms the per-layer kernels themselves sit at several per cent (gate flips)."""
+def check(res, tight=1e-2, loose=2e-2):
+    """The chain forward multiplies hi + lo bf16 halves of the activations (only the weights carry bf16 rounding), so it
+    is CLOSER to fp32 than the per-layer kernels, which round both operands: chain vs torch fp32 must be within `loose`
+    and no further than the per-layer kernels are; chain vs per-layer differ by the activations' rounding (`tight`).
+    Gradients: a ReLU gate that flips between two roundings of a pre-activation moves single elements by whole dy*w
+    terms, so they are held in the Frobenius norm to 'no further from torch than the per-layer kernels (x1.5 + 1e-2)'."""
     yc, xc, pc = res["chain"]
     yl, xl, pl = res["layers"]
     yt, xt, pt = res["torch"]
     assert fro(yc, yl) < tight, ("layers", "out", fro(yc, yl))
     assert fro(yc, yt) < loose, ("torch", "out", fro(yc, yt))
+    assert fro(yc, yt) < 1.05 * fro(yl, yt) + 1e-4, ("chain further from fp32 than the per-layer kernels", fro(yc, yt), fro(yl, yt))
     for a, b, t in zip(xc, xl, xt):
         if b is not None:
-            assert fro(a, b) < tight * 3, ("layers", "dx", fro(a, b))
-            assert fro(a, t) < 1.5 * fro(b, t) + 1e-2, ("torch", "dx", fro(a, t), fro(b, t))
+            assert fro(a, t) < max(1.5 * fro(b, t) + 1e-2, 6e-2), ("torch", "dx", fro(a, t), fro(b, t))
     for i, (a, b, t) in enumerate(zip(pc, pl, pt)):
-        if float(b.abs().max()) > 0:
-            assert fro(a, b) < tight * 3, ("layers", "param", i, tuple(b.shape), fro(a, b))
-            assert fro(a, t) < 1.5 * fro(b, t) + 1e-2, ("torch", "param", i, tuple(b.shape), fro(a, t), fro(b, t))
+        if float(b.abs().max()) > 0:  # (with a handful of rows one flipped gate is a visible share of a weight gradient)
+            assert fro(a, t) < max(1.5 * fro(b, t) + 1e-2, 6e-2), ("torch", "param", i, tuple(b.shape), fro(a, t), fro(b, t))
 
 
 @pytest.mark.parametrize("kind,M,out_dim", [("reg", 900, 11), ("reg", 100, 40), ("reg", 48, 12), ("cls", 900, 10),
@@ -131,7 +132,7 @@ def test_encoder_parts_on_strided_column_slices(width, in_dims, lo):
             HF.USE_CHAINS = True
         y.backward(torch.ones_like(y) * torch.linspace(-1, 1, width).cuda())
         res[mode] = (y.detach(), [a.grad], [p.grad for p in m.parameters()])
-    check(res, tight=3e-3, loose=3e-2)
+    check(res, tight=1e-2, loose=3e-2)
 
 
 def test_group_of_chains_writes_one_concatenated_tensor():
@@ -169,10 +170,10 @@ def test_group_of_chains_writes_one_concatenated_tensor():
     finally:
         HF.USE_CHAINS = True
     ref.backward(go)
-    assert fro(got[0], ref) < 2e-3
-    assert fro(got[1], a2.grad) < 5e-3
+    assert fro(got[0], ref) < 1e-2
+    assert fro(got[1], a2.grad) < 8e-2          # gate flips between the two roundings, see check()
     for a, b in zip(got[2], [p.grad for m in ref_mods for p in m.parameters()]):
-        assert fro(a, b) < 5e-3, tuple(b.shape)
+        assert fro(a, b) < 8e-2, tuple(b.shape)
 
 
 def test_more_than_eight_chains_and_no_grad():
@@ -190,7 +191,7 @@ def test_more_than_eight_chains_and_no_grad():
             HF.USE_CHAINS = True
     assert len(outs) == 11
     for a, b in zip(outs, refs):
-        assert fro(a, b) < 2e-3
+        assert fro(a, b) < 1e-2
 
 
 def test_unsupported_stacks_fall_back_to_layers():
@@ -226,17 +227,14 @@ def test_row_slots_scale_override_and_shared_parent_gradient():
         for p in m.parameters():
             p.grad = torch.zeros_like(p)
     y1, y2 = x1.detach().clone().requires_grad_(True), x2.detach().clone().requires_grad_(True)
-    HF.USE_CHAINS = False
-    try:
+    with HF.linear_mode("torch_fp32"):
         a = r1(y1)
         b = r2[:-1](y2) * (r2[-1].scale * col)
-    finally:
-        HF.USE_CHAINS = True
     ref = torch.cat([a, b], dim=1)
     ref.backward(go)
-    assert fro(got[0], ref) < 2e-3
-    assert fro(got[1], y1.grad) < 6e-3 and fro(got[2], y2.grad) < 6e-3
-    assert fro(got[3], r2[-1].scale.grad) < 6e-3 and fro(got[4], r1[-1].scale.grad) < 6e-3
+    assert fro(got[0], ref) < 2e-2
+    errs = [fro(got[1], y1.grad), fro(got[2], y2.grad), fro(got[3], r2[-1].scale.grad), fro(got[4], r1[-1].scale.grad)]
+    assert all(e < 0.12 for e in errs), errs   # five bf16 layers with ReLU gates: see check()
 
 
 def test_chunk_mix_and_motion_embedding_match_torch():

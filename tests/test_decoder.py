@@ -177,3 +177,140 @@ def test_decoder_two_frames_match_reference(golden, mode):
         tail = {k: v for k, v in q99.items() if k.startswith("s1_") and not k.endswith("_0") and not v < TOL_FRAME1_DEEP_Q99}
         assert not tail, tail
     assert all(v < (1e-2 if mode == "torch_fp32" else 2e-1) for v in mean_errs.values()), mean_errs
+
+
+def _frame_inputs(z, step, device):
+    from hipad_amd import synthetic as syn
+    from projects.mmdet3d_plugin.ops import feature_maps_format
+    hw = tuple(int(v) for v in z["input_hw"])
+    shapes = syn.pyramid_shapes(hw)
+    pm, wh = syn.projection_mats(hw, bs=1)
+    maps = [seeded((1, 6, 256, h, w), 800 + 10 * step + i, 0.5).to(device) for i, (h, w) in enumerate(shapes)]
+    fm = feature_maps_format(maps)
+    T = syn.ego_motion(step)
+    metas = dict(projection_mat=torch.from_numpy(pm).to(device), image_wh=torch.from_numpy(wh).to(device),
+                 timestamp=torch.tensor([0.5 * step], dtype=torch.float64, device=device),
+                 img_metas=[dict(T_global=T, T_global_inv=np.linalg.inv(T))],
+                 gt_ego_fut_cmd=torch.tensor([[0, 0, 0, 1, 0, 0]], dtype=torch.float32, device=device),
+                 target_point=torch.tensor([[3.0, 25.0]], device=device))
+    return fm, metas
+
+
+@pytest.mark.gpu
+def test_bf16_configuration_is_pinned_op_by_op(golden):
+    """The benchmarked configuration (every Linear on bf16 operands: MFMA GEMM / MLP-chain kernels) against the fp32
+    configuration -- which test_decoder_two_frames_match_reference pins to the reference's SparseOneDecoder at 1e-3..1e-4
+    -- WITHOUT letting errors compound or discrete choices diverge: the fp32 run records the live state after every op
+    of the program (both frames); the bf16 run is teacher-forced, i.e. after each op its state is compared and then
+    overwritten with the recorded one, so every op sees the fp32 run's inputs, the temporal top-k selections and the bank
+    caches included.  BASELINE.json's bf16 class: aggregated features (output of the `deformable` ops) within 1e-2,
+    every head output within 2e-2 (relative to the largest reference magnitude of the tensor)."""
+    import copy
+    from hipad_amd import functional as HF
+    z = golden("decoder_stage2")
+    dec = build_decoder(tuple(z["input_hw"]))
+    fill_parameters_by_name(dec, 4242)
+    dec = dec.cuda().eval()
+    fresh = copy.deepcopy(dec)
+
+    def record(log):
+        def probe(slot, op, state):
+            log.append((slot, op, {k: v.detach().clone() for k, v in state.items()}))
+        return probe
+
+    def force(log, errors):
+        it = iter(log)
+
+        def probe(slot, op, state):
+            rslot, rop, ref = next(it)
+            assert (rslot, rop) == (slot, op) and set(ref) == set(state), (slot, op, sorted(set(ref) ^ set(state)))
+            for k, v in state.items():
+                r = ref[k]
+                assert r.shape == v.shape, (slot, op, k, r.shape, v.shape)
+                if v.dtype.is_floating_point:
+                    err = float((v - r).abs().max() / r.abs().max().clamp_min(1e-9))
+                    errors.setdefault((op, k.split(".")[-1] if not k.startswith("out.") else k), []).append(err)
+                v.copy_(r)   # teacher forcing
+        return probe
+
+    logs, snapshots = [], []
+    with torch.no_grad(), HF.linear_mode("torch_fp32"):
+        for step in range(2):
+            snapshots.append(copy.deepcopy(dec))       # decoder + bank state BEFORE this frame
+            log = []
+            dec._probe = record(log)
+            fm, metas = _frame_inputs(z, step, "cuda")
+            dec(None, fm, metas)
+            dec._probe = None
+            logs.append(log)
+    errors = {}
+    with torch.no_grad(), HF.linear_mode("mfma_bf16"):
+        for step in range(2):
+            student = snapshots[step]
+            student._probe = force(logs[step], errors)
+            fm, metas = _frame_inputs(z, step, "cuda")
+            student(None, fm, metas)
+    worst = {k: max(v) for k, v in errors.items()}
+    print("op-by-op worst relative errors:", {f"{k[0]}:{k[1]}": round(v, 5) for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:16]})
+    aggregated = {k: v for k, v in worst.items() if k[0] == "deformable" and k[1] == "feature"}
+    heads = {k: v for k, v in worst.items() if k[1].startswith("out.")}
+    assert aggregated and heads
+    top = lambda d: sorted(((round(v, 5), k) for k, v in d.items()), reverse=True)[:6]  # noqa: E731
+    assert all(v < 1e-2 for v in aggregated.values()), top(aggregated)
+    assert all(v < 2e-2 for v in heads.values()), top(heads)
+    rest = {k: v for k, v in worst.items() if k not in aggregated and k not in heads}
+    assert all(v < 2e-2 for v in rest.values()), top(rest)
+
+
+@pytest.mark.gpu
+def test_bf16_configuration_loss_terms_track_fp32():
+    """Every loss term of the whole model (reference SparseOneDecoder.loss with target assignment, criterion.py) computed
+    from the bf16 configuration's head outputs against the same term from the fp32 configuration's, two temporal frames,
+    stochastic layers off: BASELINE.json holds losses to 1e-2 in the bf16 class.  The Hungarian assignments are a discrete
+    choice, and so are the point order of a matched poly-line, the winning trajectory mode and the class-score gate on
+    regression positives (a random-init model has near-ties: one reversed map line moved map_loss_line by 127 % in one
+    run out of two), and inside the decoder the temporal top-k selections and the class that picks an agent's motion-mode
+    anchors: the bf16 run replays the choices the fp32 run made (hipad_amd.compat.discrete_choice), so the terms compare
+    the same instances and matched pairs."""
+    import copy
+    import warnings
+    from hipad_amd import functional as HF
+    from hipad_amd.frame import SyntheticFrames, build_detector, frame_losses
+    warnings.filterwarnings("ignore")
+    torch.manual_seed(7)
+    model, _ = build_detector(stage=2, plan_queries=480)
+    model.eval()
+    model.use_grid_mask = False
+    frames = SyntheticFrames(seed=5)
+    batches = [frames.next() for _ in range(2)]
+    from hipad_amd import compat as CR
+    identity = CR.discrete_choice[0]
+    recorded = []
+    terms = {}
+    try:
+        for mode in ("torch_fp32", "mfma_bf16"):
+            m = copy.deepcopy(model)
+            if mode == "torch_fp32":
+                def choose(tag, choice):
+                    recorded.append((tag, choice.clone()))
+                    return choice
+            else:
+                replay = iter(recorded)
+
+                def choose(tag, choice):
+                    rtag, rchoice = next(replay)
+                    assert rtag == tag and rchoice.shape == choice.shape, (rtag, tag)
+                    return rchoice
+            CR.discrete_choice[0] = choose
+            with torch.no_grad(), HF.linear_mode(mode):
+                for step, (img, data) in enumerate(batches):
+                    for k, v in frame_losses(m, img, data).items():
+                        terms.setdefault((step, k), {})[mode] = float(v)
+    finally:
+        CR.discrete_choice[0] = identity
+    assert len(recorded) >= 4
+    rel = {k: abs(v["mfma_bf16"] - v["torch_fp32"]) / max(abs(v["torch_fp32"]), 1e-6) for k, v in terms.items()}
+    print("loss terms, relative difference bf16 vs fp32:", {f"{k[0]}:{k[1]}": round(v, 5) for k, v in sorted(rel.items(), key=lambda kv: -kv[1])[:10]})
+    assert len(rel) >= 30
+    bad = {k: (round(v, 5), terms[k]) for k, v in rel.items() if not v < 1e-2}
+    assert not bad, bad

@@ -135,4 +135,6 @@ def test_mlp_stack_state_dict_and_output_equal_sequential(monkeypatch):
     plain.load_state_dict(fused.state_dict())
     assert list(fused.state_dict()) == list(plain.state_dict())
     x = torch.randn(2, 900, 256).cuda()
-    assert rel_fro(fused(x), plain(x)) < 1e-3   # same kernels' arithmetic up to the order of the reduction chunks
+    # MLPStack runs the chain kernel (activations as hi + lo bf16 pairs), the plain Sequential the per-layer kernels (both
+    # operands rounded to bf16): they differ by the activations' rounding
+    assert rel_fro(fused(x), plain(x)) < 1e-2
