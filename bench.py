@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch the step kernel by kernel instead of replaying hipGraphs")
     ap.add_argument("--bs", type=int, default=1, help="frames per GPU per step")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
@@ -101,18 +101,33 @@ class DafStage2:
             d["gw"] = torch.empty_like(d["w"])
             v = (loc[..., 0] > 0) & (loc[..., 0] < 1) & (loc[..., 1] > 0) & (loc[..., 1] < 1)
             d["kept_pairs"] = int(v.sum())
+            d["rows_touched"] = self.unique_rows(d["loc"])
             self.calls.append(d)
+
+    def unique_rows(self, loc):
+        """Distinct pyramid rows the in-bounds bilinear corners of ``loc`` touch (the kernels' own index work,
+        hipad_daf_taps): the compulsory pyramid traffic of a call is rows x 1 KiB."""
+        valid, taps = self.lib.daf_taps(self.ss, self.st, loc, self.F)
+        L = self.ss.shape[1]
+        h_low, w_low, mask, base = taps[..., 0].long(), taps[..., 1].long(), taps[..., 2], taps[..., 3].long()
+        W = self.ss[:, :, 1].long()[None, None, None]                       # (1,1,1,cams,L)
+        ok = valid.bool()[..., None]
+        rows = []
+        for bit, (dh, dw) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+            sel = ok & ((mask >> bit) & 1).bool()
+            rows.append((base + (h_low + dh) * W + (w_low + dw))[sel])
+        return int(torch.unique(torch.cat(rows)).numel())
 
     # -- algorithmic bytes (SURVEY.md section 8d) -------------------------------------------
     def alg_bytes(self, d, kind):
-        """weights + locations + out/grad_out + compulsory pyramid traffic
-        min(F*C, taps*C) (each pyramid element at most once per launch), plus what the kernel writes."""
+        """weights + locations + out/grad_out + compulsory pyramid traffic (every pyramid row an
+        in-bounds corner touches, once per launch -- counted from the kernels' own index work, not the looser
+        min(F*C, taps*C) cap), plus what the kernel writes."""
         A, P = d["A"], d["P"]
         wbytes = 4 * A * P * 6 * 4 * 8
         lbytes = 4 * A * P * 6 * 2
         obytes = 4 * A * 256
-        taps = 4 * d["kept_pairs"] * 4            # bilinear taps actually taken (4 levels x 4 corners)
-        fbytes = 4 * min(self.F * 256, 256 * taps)  # compulsory pyramid traffic
+        fbytes = 4 * 256 * d["rows_touched"]       # compulsory pyramid traffic: every touched row once
         if kind == "fwd":
             return wbytes + lbytes + obytes + fbytes
         if kind == "bwd_lw":   # reads w, loc, grad_out, feat; writes grad_w, grad_loc
@@ -220,6 +235,34 @@ class Stage2Full:
             self.model.head.onedecoder_head.run_step = was
         return {k: round(float(v), 4) for k, v in losses.items()}
 
+    def frame_roofline(self, measured_ms_per_frame):
+        """roofline.frame of the JSON line (hipad_amd.roofline): one extra eager forward with per-operator accounting."""
+        from hipad_amd import roofline as RL
+        daf = self.daf
+
+        def daf_bytes(loc, kind):
+            A, P = loc.shape[1:3]
+            v = (loc[..., 0] > 0) & (loc[..., 0] < 1) & (loc[..., 1] > 0) & (loc[..., 1] < 1)
+            d = dict(A=A, P=P, kept_pairs=int(v.sum()) // loc.shape[0], rows_touched=daf.unique_rows(loc[:1].contiguous()))
+            return loc.shape[0] * daf.alg_bytes(d, kind)
+
+        img, data = self.frames.next()
+        cats = RL.census(self.model, img, data, daf_bytes)
+        return RL.frame_roofline(cats, measured_ms_per_frame)
+
+    def cpu_frame_baseline(self, seconds):
+        """The whole training frame (encoder + decoder + losses, forward + backward, fp32) on the host cores: the mirrored
+        modules on CPU tensors with oracle/ supplying the operators that exist only as HIP kernels (oracle/cpu_frame.py);
+        all host cores, count stated."""
+        from oracle import cpu_frame
+        r = cpu_frame.time_frames(seconds=seconds, plan_queries=self.plan_queries)
+        return dict(value=round(r["frames"] / r["seconds"], 4), unit="frames/s", cores=r["cores"], kind="port",
+                    sample=f"{r['frames']} whole stage-2 training frame(s) (ResNet50+FPN + decoder + losses, forward + "
+                           f"backward, fp32, batch 1, plan {self.plan_queries}) after one untimed warm-up frame, "
+                           f"{r['seconds']:.1f} s on {r['cores']} host threads: torch CPU ops for the mirrored modules, "
+                           "oracle/daf_oracle.c (anchors dealt to the threads) for the aggregation, fp32 softmax attention "
+                           "in place of the HIP kernel; optimiser step not included")
+
     def breakdown(self, reps=5):
         """ms per frame of the encoder forward, decoder forward and the rest, by HIP events, launched
         EAGERLY (so it includes launch gaps the graph replay does not have; shares, not the headline)."""
@@ -294,21 +337,34 @@ def pmc_traffic(kernel, A, P):
     return None if hit is None else hit["hbm_bytes_per_launch"]
 
 
-def roofline_of(daf):
+def roofline_of(daf, layers=6):
+    """Dominant hand-written kernel of the step (largest per-frame time = launches x average duration), measured live
+    with HIP events on the launch stream, against its algorithmic bytes; plus the same numbers for every other
+    aggregation launch (forward, grad loc+weights kernel, feature-gradient pipeline) of the four query sets."""
     kt = daf.kernel_times()
-    single = {k: v for k, v in kt.items() if k[1] in ("fwd", "bwd_lw")}  # single-kernel launches
-    dom = max(single, key=single.get)
+    table = {}
+    for (name, tag), ms in kt.items():
+        dcall = next(d for d in daf.calls if d["name"] == name)
+        alg = daf.alg_bytes(dcall, tag)
+        gbs = alg / (ms * 1e-3) / 1e9
+        table[f"{name}_{tag}"] = dict(ms=round(ms, 4), alg_mbytes=round(alg / 1e6, 1), GBs=round(gbs, 1),
+                                      frac=round(gbs / HBM_PEAK_GBS, 4), ms_per_frame=round(layers * ms, 3))
+    dom = max(kt, key=kt.get)
     dcall = next(d for d in daf.calls if d["name"] == dom[0])
     alg = daf.alg_bytes(dcall, dom[1])
     achieved = alg / (kt[dom] * 1e-3) / 1e9
-    kname = {"fwd": "daf_fwd_c256_kernel<4, true>", "bwd_lw": "daf_bwd_lw_kernel<4, true, true>"}[dom[1]]
+    kname = {"fwd": "daf_fwd_c256_kernel<4, true> (+ combine)", "bwd_lw": "daf_bwd_lw_kernel<4, true, true>",
+             "bwd_feat": "feature-gradient pipeline (daf_tap_pass x2, daf_alloc, daf_bwd_feat_kernel)"}[dom[1]]
+    pmc_name = {"fwd": "daf_fwd_c256_kernel<4, true>", "bwd_lw": "daf_bwd_lw_kernel<4, true, true>",
+                "bwd_feat": "daf_bwd_feat_kernel"}[dom[1]]
     return dict(bound="hbm", kernel=f"{kname} [{dom[0]}: A={dcall['A']} P={dcall['P']}]",
                 achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                traffic=pmc_traffic(kname, dcall["A"], dcall["P"]),
+                traffic=pmc_traffic(pmc_name, dcall["A"], dcall["P"]),
                 traffic_source="profiles/" + PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                "`bench.py --workload daf_stage2`, bytes per launch)",
                 alg_bytes_per_launch=alg, avg_launch_ms=round(kt[dom], 4),
-                all_kernels_ms={f"{k[0]}_{k[1]}": round(v, 4) for k, v in kt.items()})
+                rows_touched=dcall["rows_touched"], kept_pairs=dcall["kept_pairs"],
+                aggregation_launches=table)
 
 
 def self_launch(a):
@@ -325,6 +381,14 @@ def self_launch(a):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
+
+
+_T0 = time.perf_counter()
+
+
+def note(msg):
+    """Progress line on stderr (a long bench run must show signs of life; stdout carries only the JSON line)."""
+    print("[bench %6.1f s] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
 
 
 def main():
@@ -347,6 +411,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    note("workload built (model, warm-up frames, graph capture)")
     for _ in range(a.warmup):
         wl.step()
     barrier()
@@ -357,6 +422,7 @@ def main():
     from hipad_amd.dist import max_over_ranks
     dt = max_over_ranks(time.perf_counter() - t0, dev)
 
+    note("timed region done: %.3f ms per step" % (dt / a.steps * 1e3))
     sanity = wl.sanity() if full else None
     # eager extras run on EVERY rank: the loss path all-reduces its positive counts (reduce_mean), so a rank-0-only
     # call would leave the other ranks out of a collective
@@ -366,6 +432,10 @@ def main():
         raise SystemExit(f"bench: the training step went non-finite ({sanity}); refusing to report a throughput")
     daf = wl.daf if (full or infer) else wl
     roof = roofline_of(daf)
+    note("aggregation launches timed")
+    if full:
+        roof["frame"] = wl.frame_roofline(dt / a.steps * 1e3 / a.bs)
+        note("frame roofline census done")
     if full:
         workload = ("stage2_full: one training step (forward + the reference's losses with device-side Hungarian target "
                     "assignment [det/map/motion/ego/plan/depth terms] + backward + grad all-reduce + clip + AdamW) of "
@@ -375,9 +445,14 @@ def main():
         dtype = "bf16"
         cfg = dict(workload=workload, frames_per_gpu_per_step=a.bs, plan_queries=a.plan_queries, parallelism=f"dp{world}",
                    launch="eager" if a.eager else "hipGraph replay (fwd+bwd graph, eager RCCL all-reduce, clip+AdamW graph)",
+                   with_cp=False, with_cp_note="activation checkpointing of the backbone (reference config: with_cp=True, "
+                   "projects/configs/hipad_b2d_stage2.py:119) is OFF: 288 GB of HBM hold the activations, so the "
+                   "reference's backbone re-computation in the backward is not part of this step",
                    eager_frame_breakdown_ms=eager_breakdown, last_step=sanity, loss_terms=loss_terms,
-                   roofline_scope="dominant hand-written kernel (deformable aggregation); encoder convolutions and "
-                                  "GEMMs are MIOpen / hipBLASLt library calls")
+                   roofline_scope="`roofline`: the aggregation launch with the largest per-frame time (live HIP-event timing, "
+                                  "algorithmic bytes from the kernels' own tap indices); `roofline.frame`: sum over ALL "
+                                  "operators of the step of max(bytes / 8 TB/s, flops / 2.5 PF) against the measured step; "
+                                  "MFMA utilisation of the linear path: profiles/r02_gemm_pmc.json")
     elif infer:
         workload = ("stage2_infer: closed-loop style inference of hipad_b2d_stage2, batch 1, one 6-cam 704x256 frame per step: "
                     "encoder + decoder replayed from a hipGraph, then track ids and the result decoders (boxes, map vectors, "
@@ -397,14 +472,11 @@ def main():
                ms_per_step=round(dt / a.steps * 1e3, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
                dtype=dtype, data="synthetic", config=cfg, roofline=roof)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cb = daf.cpu_baseline(a.cpu_seconds)
-        if full:
-            cb["sample"] += ("; covers the aggregation calls only (this repo has no CPU port of the rest of the frame: the "
-                             "reference's whole decoder on CPU measured 14.8 s/frame fwd, ~156 s fwd+bwd on 8 vCPUs, "
-                             "BASELINE.md section 3) -- so it is an upper bound on whole-frame CPU frames/s")
-        out["cpu_baseline"] = cb
+        note("cpu baseline ...")
+        out["cpu_baseline"] = wl.cpu_frame_baseline(a.cpu_seconds) if full else daf.cpu_baseline(a.cpu_seconds)
     elif rank == 0:
         out["cpu_baseline"] = None
+    note("done")
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

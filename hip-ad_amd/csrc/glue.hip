@@ -86,6 +86,22 @@ __global__ __launch_bounds__(256) void motion_embed_kernel(float *__restrict__ o
   o[half + k] = (k & 1) ? cosf(ax) : sinf(ax);
 }
 
+// out[i] = 1 / (1 - p) with probability 1 - p, else 0 -- one counter-based draw per element from (seed, device step
+// counter, i): the Bernoulli keep mask of DeformableFeatureAggregation's attn_drop (reference models/blocks.py:209-212:
+// torch.rand(...) > p, .float(), / (1 - p): four launches) in one launch, a fresh mask on every replay of a hipGraph.
+__global__ __launch_bounds__(256) void keep_mask_kernel(float *__restrict__ out, long n, uint32_t thresh, float inv_keep,
+                                                        uint32_t seed, const uint32_t *__restrict__ seed_dev) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t x = seed + (seed_dev ? *seed_dev * 0x9E3779B9u : 0u);
+  x ^= (uint32_t)i * 0xC2B2AE3Du;
+  x = (x ^ (x >> 15)) * 0x2C1B3C6Du;
+  x ^= (uint32_t)(i >> 32) * 0x27D4EB2Fu + 0x165667B1u;
+  x = (x ^ (x >> 13)) * 0x297A2D39u;
+  x ^= x >> 16;
+  out[i] = x >= thresh ? inv_keep : 0.f;
+}
+
 }  // namespace hipad
 
 using namespace hipad;
@@ -104,6 +120,15 @@ int hipad_chunk_mix(float *out, const float *x0, const float *x1, const float *w
   const long total = (long)bs * out_chunks * rows * (channels / 4);
   hipLaunchKernelGGL(chunk_mix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, x0, x1,
                      t, bs, in_chunks, out_chunks, rows, channels / 4);
+  return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
+}
+
+int hipad_keep_mask(float *out, long long n, float p_drop, unsigned seed, const unsigned *seed_dev, hipad_stream_t stream) {
+  if (!out || n <= 0 || !(p_drop >= 0.f) || !(p_drop < 1.f)) return HIPAD_EINVAL;
+  const double t = (double)p_drop * 4294967296.0;
+  const uint32_t thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+  hipLaunchKernelGGL(keep_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, (long)n,
+                     thresh, 1.f / (1.f - p_drop), seed, seed_dev);
   return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
 }
 

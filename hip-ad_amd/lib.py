@@ -44,6 +44,7 @@ SIGNATURES = {
     "hipad_adamw_step": (c_int, [c_void_p] * 4 + [ctypes.c_longlong] * 2 + [ctypes.c_float] * 7
                          + [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p]),
     "hipad_lr_factor": (ctypes.c_float, [c_void_p, c_int]),
+    "hipad_keep_mask": (c_int, [c_void_p, ctypes.c_longlong, ctypes.c_float, ctypes.c_uint, c_void_p, c_void_p]),
     "hipad_chunk_mix": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
     "hipad_motion_query_embed": (c_int, [c_void_p] * 5 + [ctypes.c_longlong] + [c_int] * 7 + [c_void_p]),
     "hipad_chain_forward": (c_int, [c_void_p, c_int, c_void_p]),
@@ -563,4 +564,14 @@ def motion_query_embed(cls, box, table, freq, sin_col, cos_col):
         check(lib.hipad_motion_query_embed(out.data_ptr(), cls.data_ptr(), box.data_ptr(), table.data_ptr(), freq.data_ptr(),
                                            bs * A, ncls, D, sin_col, cos_col, modes, ts, half, stream_ptr(cls.device)),
               "hipad_motion_query_embed")
+    return out
+
+
+def keep_mask(shape, p_drop, seed, seed_dev, device):
+    """Bernoulli keep mask scaled by 1 / (1 - p) in one launch; ``seed_dev``: device int32 step counter or None."""
+    lib = load()
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        check(lib.hipad_keep_mask(out.data_ptr(), out.numel(), float(p_drop), int(seed) & 0xFFFFFFFF, _ptr(seed_dev),
+                                  stream_ptr(device)), "hipad_keep_mask")
     return out

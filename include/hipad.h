@@ -422,8 +422,13 @@ int hipad_pack_weights(unsigned short *const *dst, unsigned short *const *dst_t,
  *   cls (n_anchor, num_classes) logits; box (n_anchor, box_dim); table (num_classes, modes, steps, 2);
  *   freq (half_dim) = 10000 ** (2 * (k / 2) / half_dim); out (n_anchor, modes, 2 * half_dim) = [embed(y) | embed(x)],
  *   embed(v)[k] = sin or cos (k odd) of v * 2 pi / freq[k], same operation order as the torch expression.
+ * hipad_keep_mask.  Replaces: the Bernoulli keep mask of DeformableFeatureAggregation's attn_drop (reference
+ *   models/blocks.py:209-212; rand, compare, cast, rescale = four launches): out[i] = 1 / (1 - p_drop) with probability
+ *   1 - p_drop else 0, drawn from (seed, *seed_dev, i) -- seed_dev (may be NULL) is a device step counter, so a replayed
+ *   hipGraph draws a fresh mask every step.
  * ---------------------------------------------------------------------------------- */
 #define HIPAD_MIX_MAX 16
+int hipad_keep_mask(float *out, long long n, float p_drop, unsigned seed, const unsigned *seed_dev, hipad_stream_t stream);
 int hipad_chunk_mix(float *out, const float *x0, const float *x1, const float *weights, int bs, int in_chunks,
                     int out_chunks, int rows, int channels, hipad_stream_t stream);
 int hipad_motion_query_embed(float *out, const float *cls, const float *box, const float *table, const float *freq,

@@ -30,7 +30,14 @@ def lib():
         _lib = ctypes.CDLL(_SO)
         for name in ("hipad_oracle_daf_forward", "hipad_oracle_daf_backward", "hipad_oracle_daf_taps"):
             getattr(_lib, name).restype = ctypes.c_int
+        _lib.hipad_oracle_set_threads(1)   # the checker walks the reference's index space sequentially
     return _lib
+
+
+def set_threads(n):
+    """Threads of the C restatement (1 = the sequential checker; >1 only for bench.py's cpu_baseline timing: anchors are
+    dealt to threads and grad_feat is scattered with atomic adds, like the reference CUDA kernel)."""
+    lib().hipad_oracle_set_threads(int(n))
 
 
 def _f32(x):

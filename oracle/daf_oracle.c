@@ -35,9 +35,22 @@
  * tests/golden/ (see tests/golden/make_golden.py and tests/test_oracle_golden.py).
  */
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stddef.h>
 #include <stdint.h>
 #include <string.h>
+
+/*
+ * Threads (bench.py's cpu_baseline leg only; the checker default is ONE thread = the sequential order described above).
+ * Anchors are dealt to threads for everything an anchor owns (its output row, grad_loc, grad_w); grad_feat is scattered
+ * in a second pass in which thread t applies the updates of pyramid rows r with r % threads == t, in the sequential
+ * order.  Both passes give bitwise the one-thread result (tests/test_oracle_golden.py checks it).
+ */
+static int g_threads = 1;
+void hipad_oracle_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int hipad_oracle_get_threads(void) { return g_threads; }
 
 typedef struct {
     int h_low, w_low, h_high, w_high;
@@ -107,6 +120,7 @@ int hipad_oracle_daf_forward(const float *feat, const int32_t *spatial_shape,
         memset(acc, 0, n_out * sizeof(double));
     }
     memset(out, 0, n_out * sizeof(float));
+#pragma omp parallel for collapse(2) schedule(dynamic, 4) num_threads(g_threads)
     for (int b = 0; b < batch_size; ++b)
         for (int a = 0; a < num_anchors; ++a) {
             const int64_t anchor_index = (int64_t)b * num_anchors + a;
@@ -149,6 +163,46 @@ int hipad_oracle_daf_forward(const float *feat, const int32_t *spatial_shape,
     return 0;
 }
 
+/* grad_feat of the rows owned by thread `tid` of `nt` (row r belongs to thread r % nt): every thread walks the whole
+ * index space in the sequential order but applies only its rows' updates, so each row receives its addends in exactly the
+ * order of the one-thread code (bitwise the same result), without atomics. */
+static void feat_scatter_rows(const int32_t *spatial_shape, const int32_t *scale_start_index, const float *loc,
+                              const float *weights, const float *grad_out, float *grad_feat, double *gf64,
+                              int batch_size, int num_cams, int num_feat, int num_embeds, int num_scale, int num_anchors,
+                              int num_pts, int num_groups, int tid, int nt) {
+    const int gdim = num_embeds / num_groups;
+    for (int b = 0; b < batch_size; ++b)
+        for (int a = 0; a < num_anchors; ++a) {
+            const int64_t anchor_index = (int64_t)b * num_anchors + a;
+            const float *go = grad_out + anchor_index * num_embeds;
+            for (int p = 0; p < num_pts; ++p)
+                for (int cam = 0; cam < num_cams; ++cam) {
+                    const int64_t loc_offset = ((anchor_index * num_pts + p) * num_cams + cam) << 1;
+                    const float loc_w = loc[loc_offset], loc_h = loc[loc_offset + 1];
+                    if (loc_rejected(loc_w, loc_h)) continue;
+                    for (int s = 0; s < num_scale; ++s) {
+                        const int cs = cam * num_scale + s;
+                        const int64_t base = ((int64_t)b * num_feat + scale_start_index[cs]) * num_embeds;
+                        const int h = spatial_shape[2 * cs], w = spatial_shape[2 * cs + 1];
+                        taps_t t;
+                        make_taps(h, w, num_embeds, pix(loc_h, h), pix(loc_w, w), base, &t);
+                        const float cw[4] = {t.hh * t.hw, t.hh * t.lw, t.lh * t.hw, t.lh * t.lw};
+                        const int64_t cp[4] = {t.p1, t.p2, t.p3, t.p4};
+                        const int cin[4] = {t.in1, t.in2, t.in3, t.in4};
+                        const int64_t wbase = ((loc_offset >> 1) * num_scale + s) * num_groups;
+                        for (int k = 0; k < 4; ++k) {
+                            if (!cin[k] || (int)((cp[k] / num_embeds) % nt) != tid) continue;
+                            for (int c = 0; c < num_embeds; ++c) {
+                                const float top = go[c] * weights[wbase + c / gdim];
+                                if (gf64) gf64[cp[k] + c] += (double)(cw[k] * top);
+                                else grad_feat[cp[k] + c] += cw[k] * top;
+                            }
+                        }
+                    }
+                }
+        }
+}
+
 /*
  * Backward (cu:190-262 + cu:62-126).  grad_* are ACCUMULATED INTO (the reference's
  * caller passes zero-initialised tensors, ops/deformable_aggregation.py:55-57).
@@ -170,6 +224,8 @@ int hipad_oracle_daf_backward(const float *feat, const int32_t *spatial_shape,
         if (!gf64) return -2;
         memset(gf64, 0, n_feat * sizeof(double));
     }
+    const int mt = g_threads > 1; /* several threads: grad_feat is scattered in the second, row-partitioned pass */
+#pragma omp parallel for collapse(2) schedule(dynamic, 4) num_threads(g_threads)
     for (int b = 0; b < batch_size; ++b)
         for (int a = 0; a < num_anchors; ++a) {
             const int64_t anchor_index = (int64_t)b * num_anchors + a;
@@ -200,29 +256,37 @@ int hipad_oracle_daf_backward(const float *feat, const int32_t *spatial_shape,
                                 v1 = feat[t.p1 + c];
                                 gh -= t.hw * v1;
                                 gw -= t.hh * v1;
-                                if (acc64) gf64[t.p1 + c] += (double)(w1 * top);
-                                else grad_feat[t.p1 + c] += w1 * top;
+                                if (!mt) {
+                                    if (acc64) gf64[t.p1 + c] += (double)(w1 * top);
+                                    else grad_feat[t.p1 + c] += w1 * top;
+                                }
                             }
                             if (t.in2) {
                                 v2 = feat[t.p2 + c];
                                 gh -= t.lw * v2;
                                 gw += t.hh * v2;
-                                if (acc64) gf64[t.p2 + c] += (double)(w2 * top);
-                                else grad_feat[t.p2 + c] += w2 * top;
+                                if (!mt) {
+                                    if (acc64) gf64[t.p2 + c] += (double)(w2 * top);
+                                    else grad_feat[t.p2 + c] += w2 * top;
+                                }
                             }
                             if (t.in3) {
                                 v3 = feat[t.p3 + c];
                                 gh += t.hw * v3;
                                 gw -= t.lh * v3;
-                                if (acc64) gf64[t.p3 + c] += (double)(w3 * top);
-                                else grad_feat[t.p3 + c] += w3 * top;
+                                if (!mt) {
+                                    if (acc64) gf64[t.p3 + c] += (double)(w3 * top);
+                                    else grad_feat[t.p3 + c] += w3 * top;
+                                }
                             }
                             if (t.in4) {
                                 v4 = feat[t.p4 + c];
                                 gh += t.lw * v4;
                                 gw += t.lh * v4;
-                                if (acc64) gf64[t.p4 + c] += (double)(w4 * top);
-                                else grad_feat[t.p4 + c] += w4 * top;
+                                if (!mt) {
+                                    if (acc64) gf64[t.p4 + c] += (double)(w4 * top);
+                                    else grad_feat[t.p4 + c] += w4 * top;
+                                }
                             }
                             const float val = (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
                             /* cu:122-125 */
@@ -249,6 +313,18 @@ int hipad_oracle_daf_backward(const float *feat, const int32_t *spatial_shape,
                     }
                 }
         }
+    if (mt) {
+#pragma omp parallel num_threads(g_threads)
+        {
+#ifdef _OPENMP
+            const int tid = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+            const int tid = 0, nt = 1;
+#endif
+            feat_scatter_rows(spatial_shape, scale_start_index, loc, weights, grad_out, grad_feat, gf64, batch_size,
+                              num_cams, num_feat, num_embeds, num_scale, num_anchors, num_pts, num_groups, tid, nt);
+        }
+    }
     if (acc64) {
         for (size_t i = 0; i < n_feat; ++i) grad_feat[i] += (float)gf64[i];
         __builtin_free(gf64);

@@ -57,8 +57,8 @@ class FlashMHA(nn.Module):
         if q is k and k is v:
             return HF.linear(q, W, b).split(E, dim=-1)
         if q is k:
-            qk = HF.linear(q, W, b, rows=(0, 2 * E))
-            return qk[..., :E], qk[..., E:], HF.linear(v, W, b, rows=(2 * E, 3 * E))
+            qp, kp = HF.linear(q, W, b, rows=(0, 2 * E)).split(E, dim=-1)   # one split: its backward is one cat
+            return qp, kp, HF.linear(v, W, b, rows=(2 * E, 3 * E))
         return (HF.linear(q, W, b, rows=(0, E)), HF.linear(k, W, b, rows=(E, 2 * E)),
                 HF.linear(v, W, b, rows=(2 * E, 3 * E)))
 

@@ -100,6 +100,13 @@ class DeformableFeatureAggregation(BaseModule):
             return None
         # one Bernoulli draw per (anchor, camera, point), shared by levels and groups, scaled to
         # keep the expectation (reference blocks.py:209-212; drawn on the device here)
+        if torch.device(device).type == "cuda":
+            from hipad_amd import lib as _lib
+            if not hasattr(self, "_mask_seed"):
+                self._mask_seed = HF.new_call_site_seed()
+            # one launch, a fresh draw per step from the device-side dropout clock (replayable from a hipGraph)
+            return _lib.keep_mask((bs, num_anchor, self.num_cams, self.num_pts), self.attn_drop, self._mask_seed,
+                                  HF.dropout_clock(device), device)
         keep = torch.rand(bs, num_anchor, self.num_cams, self.num_pts, device=device) > self.attn_drop
         return keep.float() / (1.0 - self.attn_drop)
 

@@ -70,6 +70,7 @@ class _FeatureGradSink(Function):
         ctx.holder = holder = {"bufs": {}}  # one accumulation buffer per stream that runs aggregation backwards
         out._hipad_grad_holder = holder
         token = torch.zeros((), dtype=feat.dtype, device=feat.device)
+        holder["zero"] = token.detach()     # the (constant) gradient every consumer returns for its token edge
         return out, token
 
     @staticmethod
@@ -131,7 +132,9 @@ class DeformableAggregationFunction(Function):
             grad_feat = ctx.holder["bufs"].get(key)
             if grad_feat is None:
                 grad_feat = ctx.holder["bufs"][key] = torch.zeros_like(feat)
-            grad_token = torch.zeros((), dtype=feat.dtype, device=feat.device)
+            grad_token = ctx.holder.get("zero")
+            if grad_token is None:
+                grad_token = torch.zeros((), dtype=feat.dtype, device=feat.device)
         elif need_feat:
             grad_feat = ret_feat = torch.zeros_like(feat)
         if _CROSS_CHECK and grad_feat is not None:

@@ -270,3 +270,20 @@ def test_chunk_mix_and_motion_embedding_match_torch():
     assert got.shape == want.shape
     # sin / cos of arguments up to ~1e3 rad: a last-bit difference in the argument moves the value by ~1e-4
     assert float((got - want).abs().max()) < 2e-3 and float((got - want).abs().mean()) < 1e-5
+
+
+def test_keep_mask_statistics_and_clock():
+    from hipad_amd import functional as HF
+    from hipad_amd import lib
+    clock = HF.dropout_clock("cuda")
+    a = lib.keep_mask((1, 900, 6, 13), 0.15, 1234, clock, torch.device("cuda"))
+    b = lib.keep_mask((1, 900, 6, 13), 0.15, 1234, clock, torch.device("cuda"))
+    assert torch.equal(a, b)                                   # same (seed, clock) -> same mask
+    vals = torch.unique(a)
+    assert vals.numel() == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1 / 0.85) < 1e-6
+    assert abs(float((a == 0).float().mean()) - 0.15) < 0.01   # 70 200 draws: sigma = 0.0013
+    HF.advance_dropout_clock("cuda")
+    c = lib.keep_mask((1, 900, 6, 13), 0.15, 1234, clock, torch.device("cuda"))
+    assert 0.2 < float((a != c).float().mean()) < 0.3         # independent masks differ in 2 p (1 - p) = 25.5 % of the slots
+    d = lib.keep_mask((1, 900, 6, 13), 0.15, 99, clock, torch.device("cuda"))
+    assert 0.2 < float((c != d).float().mean()) < 0.3
