@@ -290,15 +290,75 @@ def discrete(tag, choice):
     return discrete_choice[0](tag, choice)
 
 
+class CountExchange:
+    """Cross-rank mean of the losses' positive counts (mmdet ``reduce_mean``, reference sparse_onedecoder.py:1134, 1190,
+    1292) for a step whose kernels are captured in hipGraphs: a collective cannot sit inside a captured graph, so the
+    counts go through a static buffer in three phases:
+
+      collect  ``reduce_mean`` copies each local count vector into the buffer (inside graph 1: the forward + the target
+               assignment) and returns the local value;
+      exchange ONE eager all-reduce of the buffer between the graphs (``all_reduce``), mean over ranks;
+      use      ``reduce_mean`` hands out the reduced values from the buffer, in the same call order (inside graph 2: the
+               loss arithmetic + backward).
+
+    Eager steps run the same three phases, so eager and replayed steps normalise identically.  ``mode`` is "direct"
+    outside such a step: the collective runs at the call (and raises under capture instead of silently skipping)."""
+
+    SIZE = 256
+
+    def __init__(self):
+        self.mode, self.buf, self.cursor, self.filled = "direct", None, 0, 0
+
+    def _buffer(self, device):
+        if self.buf is None or self.buf.device != device:
+            self.buf = torch.zeros(self.SIZE, dtype=torch.float32, device=device)
+        return self.buf
+
+    def begin(self, mode):
+        if mode not in ("direct", "collect", "use"):
+            raise ValueError(mode)
+        if mode == "use" and self.filled == 0:
+            raise RuntimeError("CountExchange: 'use' phase without a preceding 'collect' phase")
+        if mode == "collect":
+            self.filled = 0
+        self.mode, self.cursor = mode, 0
+
+    def all_reduce(self, group=None):
+        """Mean over the ranks of everything collected (one collective; a no-op for a single process)."""
+        import torch.distributed as dist
+        if self.filled and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            part = self.buf[: self.filled]
+            dist.all_reduce(part, group=group)
+            part.div_(dist.get_world_size(group))
+
+    def exchange(self, tensor):
+        n = tensor.numel()
+        buf = self._buffer(tensor.device)
+        if self.cursor + n > buf.numel():
+            raise RuntimeError("CountExchange: buffer too small")
+        part = buf[self.cursor:self.cursor + n]
+        self.cursor += n
+        if self.mode == "collect":
+            part.copy_(tensor.detach().reshape(-1).to(torch.float32))
+            self.filled = max(self.filled, self.cursor)
+            return tensor
+        return part.view(tensor.shape).to(tensor.dtype)
+
+
+count_exchange = CountExchange()
+
+
 def reduce_mean(tensor):
-    """All-reduce(mean) across ranks when torch.distributed is initialised (mmdet.core.reduce_mean)."""
+    """All-reduce(mean) across ranks when torch.distributed is initialised (mmdet.core.reduce_mean); inside a
+    CountExchange step the value travels through its static buffer (see there)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()):
+    if count_exchange.mode != "direct":
+        return count_exchange.exchange(tensor)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return tensor
     if tensor.is_cuda and torch.cuda.is_current_stream_capturing():
-        # inside a captured step the positive counts stay per rank (no collective in the graph); the only
-        # exchange of a replayed step is the flat-gradient all-reduce between the two graphs
-        return tensor
+        raise RuntimeError("reduce_mean: a collective cannot run inside a captured hipGraph; run the step through "
+                           "hipad_amd.compat.count_exchange (collect / all_reduce / use), as hipad_amd.frame does")
     tensor = tensor.clone()
     dist.all_reduce(tensor.div_(dist.get_world_size()), op=dist.ReduceOp.SUM)
     return tensor

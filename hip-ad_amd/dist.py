@@ -55,6 +55,7 @@ class FlatGrads:
         self._comm = torch.empty(total, dtype=comm_dtype, device=ref.device) if comm_dtype not in (None, ref.dtype) else None
         self._views = [p.grad for p in self.params]
         self._loose = []
+        self.split = total     # element offset where the SECOND segment (gradients produced late in the backward) starts
 
     # ---- gradients autograd accumulates itself -----------------------------------------------------
     # With ``p.grad`` preset to a (zeroed) view, autograd's AccumulateGrad runs one ``grad += new`` kernel per
@@ -65,15 +66,35 @@ class FlatGrads:
         """Parameters whose id is not in ``inplace_ids`` get the None-then-gather treatment from now on."""
         self._loose = [(p, v) for p, v in zip(self.params, self._views) if id(p) not in inplace_ids]
 
+    def set_split(self, first_late_param):
+        """Two segments for an all-reduce that overlaps the backward: [0, split) holds the gradients the backward
+        finishes first (the decoder's), [split, end) the rest (the image encoder's); ``first_late_param`` is the first
+        parameter of the second segment (parameters are laid out in the order given to the constructor)."""
+        for p, off in zip(self.params, self.offsets):
+            if p is first_late_param:
+                self.split = off
+                return
+        raise ValueError("parameter not in this buffer")
+
+    def _segment(self, which):
+        if which is None:
+            return self._loose
+        off_of = {id(p): off for p, off in zip(self.params, self.offsets)}
+        early = [(p, v) for p, v in self._loose if off_of[id(p)] < self.split]
+        return early if which == "early" else [(p, v) for p, v in self._loose if off_of[id(p)] >= self.split]
+
     def before_backward(self):
         for p, _ in self._loose:
             p.grad = None
 
-    def after_backward(self):
-        if not self._loose:
+    def after_backward(self, which=None):
+        """Gather the gradients autograd accumulated itself into the flat buffer; ``which`` = "early" / "late" limits
+        it to one segment (the early segment is gathered -- and can be reduced -- before the late backward has run)."""
+        loose = self._segment(which)
+        if not loose:
             return
         dst, src = [], []
-        for p, view in self._loose:
+        for p, view in loose:
             g = p.grad
             if g is not None and g.data_ptr() != view.data_ptr():
                 dst.append(view)
@@ -95,19 +116,24 @@ class FlatGrads:
                 if g is not None:
                     p.grad.copy_(g)
 
-    def all_reduce_mean(self, group=None):
-        """Average the flat gradient over the ranks with one collective."""
+    def all_reduce_mean(self, group=None, segment=None):
+        """Average the flat gradient (or one segment of it: "early" = [0, split), "late" = [split, end)) over the ranks
+        with one collective.  Runs on the CURRENT stream: the caller puts it on a side stream to overlap it with compute."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return
         world = dist.get_world_size(group)
+        lo, hi = (0, self.flat.numel()) if segment is None else ((0, self.split) if segment == "early" else (self.split, self.flat.numel()))
+        if hi <= lo:
+            return
+        part = self.flat[lo:hi]
         if self._comm is not None:
-            self._comm.copy_(self.flat)
-            dist.all_reduce(self._comm, group=group)
-            self.flat.copy_(self._comm)
-            self.flat.div_(world)
+            wire = self._comm[lo:hi]
+            wire.copy_(part)
+            dist.all_reduce(wire, group=group)
+            part.copy_(wire)
         else:
-            dist.all_reduce(self.flat, group=group)
-            self.flat.div_(world)
+            dist.all_reduce(part, group=group)
+        part.div_(world)
 
 
 def broadcast_parameters(module, src=0, group=None):

@@ -98,14 +98,20 @@ class TrainStep:
     projects/configs/hipad_b2d_stage2.py:629-641; data parallel as apis/mmdet_train.py:97-102)."""
 
     def __init__(self, model, cfg, comm_dtype=None, capturable=False):
+        import torch.distributed as dist
         from .dist import broadcast_parameters
         from .optim import FlatAdamW
         self.model = model
         broadcast_parameters(model)
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         opt = cfg["optimizer"]
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         bb = [p for n, p in named if n.startswith("img_backbone")]
-        rest = [p for n, p in named if not n.startswith("img_backbone")]
+        # flat layout = [decoder + depth heads | FPN | backbone]: the first segment's gradients are complete when the
+        # decoder's backward has run, so its all-reduce can travel while the encoder's backward computes the rest
+        early = [p for n, p in named if not n.startswith(("img_backbone", "img_neck"))]
+        neck = [p for n, p in named if n.startswith("img_neck")]
+        rest = early + neck
         mult = opt["paramwise_cfg"]["custom_keys"]["img_backbone"]["lr_mult"]
         self.max_norm = cfg["optimizer_config"]["grad_clip"]["max_norm"]
         # parameters, gradients and AdamW moments in flat buffers; clip + step = two launches
@@ -116,32 +122,146 @@ class TrainStep:
                              max_iters=int(runner.get("max_iters", 0)))
         self.params = self.opt.params
         self.grads = self.opt.grads
+        late = neck + bb
+        if late:
+            self.grads.set_split(late[0])
+        self._early_params = early
         self._loosened = False
+        self._comm_stream = None
 
     @property
     def grad_norm(self):
         """Total gradient norm before clipping of the last update (device scalar)."""
         return self.opt.grad_norm
 
-    def forward_backward(self, img, data):
+    # ---- the step in three parts (each capturable as one hipGraph; the collectives sit BETWEEN them) ----------------
+    def part_forward(self, img, data, keep_levels=False):
+        """Encoder + decoder forward; with more than one rank also the target assignment and the positive counts the
+        losses normalise by (compat.CountExchange "collect": they are all-reduced before part_loss_backward).
+        ``keep_levels``: remember the pyramid levels as the cut point of a two-part backward (eager steps only)."""
+        from .compat import count_exchange
+        det = self.model
+        self._data = data
+        self._cut = None
+        if OBJECTIVE == "surrogate":
+            feature_maps, self._depths = det.extract_feat(img, True, data)
+            self._outs = det.head(img, feature_maps, data)
+            return
+        feature_maps, self._depths = det.extract_feat(img, True, data)
+        if keep_levels:
+            self._cut = getattr(feature_maps[0], "_hipad_levels", None)
+        with torch.autocast("cuda", dtype=DECODER_DTYPE, enabled=DECODER_DTYPE != torch.float32):
+            self._outs = det.head(img, feature_maps, data)
+        if self.world > 1:
+            count_exchange.begin("collect")
+            try:
+                det.head.onedecoder_head.positive_counts(*self._outs, data)
+            finally:
+                count_exchange.begin("direct")
+
+    def exchange_counts(self):
+        from .compat import count_exchange
+        if self.world > 1 and OBJECTIVE != "surrogate":
+            count_exchange.all_reduce()
+
+    def _objective(self):
+        """Sum of the loss terms of the kept forward outputs (positive counts from the exchange when there are ranks)."""
+        from .compat import count_exchange
+        det, data = self.model, self._data
+        if OBJECTIVE == "surrogate":
+            return surrogate_objective(self._outs, self._depths)
+        if self.world > 1:
+            count_exchange.begin("use")
+        try:
+            losses = det.head.loss(self._outs, data)
+        finally:
+            count_exchange.begin("direct")
+        if self._depths is not None and "gt_depth" in data:
+            losses["loss_dense_depth"] = det.depth_branch.loss(self._depths, data["gt_depth"])
+        loss = None
+        for v in losses.values():
+            loss = v if loss is None else loss + v
+        return loss
+
+    def part_loss_backward(self, whole=False):
+        """Losses (normalised by the exchanged counts) + the backward down to the pyramid levels: every gradient of
+        the first flat segment is complete afterwards.  ``whole=True`` (or no kept cut point) runs the entire backward in
+        one call, as the captured steps do."""
         from . import functional as HF
-        loss = _frame_loss(self.model, img, data)
+        from .compat import count_exchange
+        loss = self._objective()
         self.grads.before_backward()
-        loss.backward()
-        self.grads.after_backward()
+        levels = [] if whole else [t for t in (self._cut or []) if t.requires_grad]
+        self._levels, self._cut = levels, None
+        if levels:
+            torch.autograd.backward([loss], inputs=self._early_params + levels)
+            self.grads.after_backward("early")
+        else:  # frozen encoder: everything is in the first part
+            loss.backward()
+            self.grads.after_backward()
+        self._outs = self._depths = None
+        return loss
+
+    def part_backward_encoder(self):
+        """The rest of the backward: FPN + backbone, from the gradients of the pyramid levels."""
+        from . import functional as HF
+        levels = self._levels
+        if levels:
+            torch.autograd.backward(levels, [t.grad for t in levels])
+            for t in levels:
+                t.grad = None
+            self.grads.after_backward("late")
+        self._levels = None
         if not self._loosened:  # after the first backward it is known which gradients our kernels write in place
             self.grads.loosen(HF.INPLACE_PARAMS)
             self._loosened = True
+
+    def forward_backward(self, img, data):
+        self.part_forward(img, data, keep_levels=True)
+        self.exchange_counts()
+        loss = self.part_loss_backward()
+        self.part_backward_encoder()
         return loss
+
+    # ---- gradient all-reduce overlapped with the encoder's backward --------------------------------------------------
+    def reduce_early(self):
+        """Start the all-reduce of the first segment on the communication stream (call after part_loss_backward)."""
+        if self.world == 1:
+            return
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream()
+        self._comm_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._comm_stream):
+            self.grads.all_reduce_mean(segment="early")
+
+    def reduce_late(self):
+        """All-reduce the second segment and join the communication stream (call after part_backward_encoder)."""
+        if self.world == 1:
+            return
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream()
+        self._comm_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._comm_stream):
+            self.grads.all_reduce_mean(segment="late")
+        torch.cuda.current_stream().wait_stream(self._comm_stream)
 
     def update(self):
         self.opt.step(zero_grad=True)  # the kernel clears each gradient once it has been applied
 
     def __call__(self, img, data):
         from . import functional as HF
-        loss = self.forward_backward(img, data)  # gradients are zero here: update() clears what it applied
-        self.grads.check_views()
-        self.grads.all_reduce_mean()
+        self.part_forward(img, data, keep_levels=True)
+        self.exchange_counts()
+        loss = self.part_loss_backward()  # gradients are zero here: update() clears what it applied
+        if img.is_cuda:
+            self.reduce_early()
+            self.part_backward_encoder()
+            self.grads.check_views()
+            self.reduce_late()
+        else:
+            self.part_backward_encoder()
+            self.grads.check_views()
+            self.grads.all_reduce_mean()
         self.update()
         HF.advance_dropout_clock(img.device)
         return loss
@@ -154,8 +274,9 @@ class GraphedTrainStep:
     Everything the step reads that changes from frame to frame lives in static device buffers filled
     OUTSIDE the graph (images, timestamp, ego-motion transform, GridMask parameters; the dropout clock
     and the instance-bank caches are device state updated in place INSIDE it), so the captured work has
-    no host dependency.  Graph A = zero grads + forward + objective + backward; the gradient
-    all-reduce runs eagerly between A and B when there is more than one rank; graph B = clip + AdamW.
+    no host dependency.  The collectives sit between the graphs (see the capture code and ``_replay``): with several
+    ranks the positive counts of the losses are all-reduced between the forward graph and the loss + backward graph
+    (compat.CountExchange), the flat gradient between that one and the clip + AdamW graph.
     Tracking-id bookkeeping (InstanceBank.get_instance_id: data-dependent shapes, inference only) is
     left out of the captured step.
     """
@@ -216,17 +337,44 @@ class GraphedTrainStep:
         self._feed(*frames.next())
         if self.debug_hook is not None:
             self.debug_hook("before_capture")
-        self.graph_a = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_a):
-            self.loss = self._fwd_bwd()
+        # one rank:      graph 1 = forward + losses + backward;                                   graph 2 = clip + AdamW
+        # several ranks: graph 1 = forward + target assignment + positive counts;  [counts all-reduce];
+        #                graph 2 = losses + backward;  [gradient all-reduce];                      graph 3 = clip + AdamW
+        # The two-part backward (decoder, then encoder, so that the decoder segment's all-reduce could travel meanwhile)
+        # is used by the eagerly launched step (TrainStep.__call__) only: captured, the encoder's backward as a separate
+        # autograd.backward call made ROCm 7.2 die in capture_end in every arrangement tried (tools/diag_graph_split.py,
+        # DESIGN.md section 4), and there is no 2-GPU box in this build loop to debug an in-graph overlap on.
+        import os
+        self.split_forward = self.world > 1 or os.environ.get("HIPAD_SPLIT_FORWARD") == "1"
+        self.graph_f = torch.cuda.CUDAGraph()
+        self.graph_l = None
+        if self.split_forward:
+            with torch.cuda.graph(self.graph_f):
+                self.inner.part_forward(self.img, self.data)
+            self.graph_l = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_l, pool=self.graph_f.pool()):
+                self.loss = self.inner.part_loss_backward(whole=True)
+                self.inner.part_backward_encoder()
+        else:
+            with torch.cuda.graph(self.graph_f):
+                self.inner.part_forward(self.img, self.data)
+                self.loss = self.inner.part_loss_backward(whole=True)
+                self.inner.part_backward_encoder()
         self.graph_b = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+        with torch.cuda.graph(self.graph_b, pool=self.graph_f.pool()):
             self._update()
         if self.debug_hook is not None:
             self.debug_hook("after_capture")
         # the capture itself did not execute the work: replay once so the banks hold this frame's state
-        self.graph_a.replay()
-        self.inner.grads.all_reduce_mean()
+        self._replay()
+
+    def _replay(self):
+        self.graph_f.replay()
+        if self.graph_l is not None:
+            self.inner.exchange_counts()
+            self.graph_l.replay()
+        if self.world > 1:
+            self.inner.grads.all_reduce_mean()
         self.graph_b.replay()
 
     def _feed(self, img, data):
@@ -254,7 +402,11 @@ class GraphedTrainStep:
 
     def _fwd_bwd(self):
         # gradients start at zero: FlatGrads allocates them so and every update() clears them again
-        return self.inner.forward_backward(self.img, self.data)
+        self.inner.part_forward(self.img, self.data)
+        self.inner.exchange_counts()
+        loss = self.inner.part_loss_backward(whole=True)
+        self.inner.part_backward_encoder()
+        return loss
 
     def _update(self):
         from . import functional as HF
@@ -269,10 +421,7 @@ class GraphedTrainStep:
 
     def __call__(self):
         self._feed(*self.frames.next())
-        self.graph_a.replay()
-        if self.world > 1:
-            self.inner.grads.all_reduce_mean()
-        self.graph_b.replay()
+        self._replay()
         return self.loss
 
 

@@ -431,6 +431,34 @@ class DecoderLoss:
     truth is tiled, every op (costs, the Hungarian kernel, scatters, loss formulas) runs once for the six layers,
     and only the final reductions are per layer (each layer has its own ``num_pos``)."""
 
+    def positive_counts(self, det_output, map_output, ego_output, plan_output, motion_output, scenes_output, data):
+        """Phase 1 of a data-parallel step (hipad_amd.compat.CountExchange): the target assignment of the matched tasks
+        and their positive counts, which ``reduce_mean`` hands to the exchange buffer -- in the order ``loss`` asks for
+        them again.  The assignments are kept and reused by the following ``loss`` call (not recomputed)."""
+        gt = data.get("gt_padded") or pad_ground_truth(data)
+        self._sampled = {}
+        with torch.no_grad():
+            if "det" in self.task_select:
+                self._sampled["det_"] = self._sample_targets(det_output, gt["det"], self.det_sampler, self.det_reg_weights)
+                reduce_mean(self._sampled["det_"][-1])
+            if "map" in self.task_select:
+                self._sampled["map_"] = self._sample_targets(map_output, gt["map"], self.map_sampler, self.map_reg_weights)
+                reduce_mean(self._sampled["map_"][-1])
+            if "motion" in self.task_select:
+                layers = len(motion_output["classification"])
+                bs = motion_output["prediction"][0].shape[0]
+                det_index = _tile(self.det_sampler.indices[-bs:], layers)
+                reduce_mean((det_index >= 0).reshape(layers, -1).sum(dim=1).to(torch.float32))
+
+    def _sample_targets(self, outs, gt, sampler, reg_weights):
+        layers = len(outs["classification"])
+        cls = _stack_layers(outs["classification"]).detach()
+        reg = _stack_layers(outs["prediction"])[..., : len(reg_weights)].detach()
+        cls_target, reg_target, weights = sampler.sample(cls, reg, {k: _tile(v, layers) for k, v in gt.items()})
+        sampler.layers = layers
+        matched = torch.logical_not(torch.all(reg_target == 0, dim=-1))
+        return cls_target, reg_target, weights, matched, matched.reshape(layers, -1).sum(dim=1).to(torch.float32)
+
     def loss(self, det_output, map_output, ego_output, plan_output, motion_output, scenes_output, data):
         gt = data.get("gt_padded") or pad_ground_truth(data)
         losses = {}
@@ -459,10 +487,12 @@ class DecoderLoss:
         cls = _stack_layers(outs["classification"])
         reg = _stack_layers(outs["prediction"])[..., : len(reg_weights)]
         qt = None if outs["quality"][0] is None else _stack_layers(outs["quality"])
-        cls_target, reg_target, weights = sampler.sample(cls, reg, {k: _tile(v, layers) for k, v in gt.items()})
-        sampler.layers = layers
-        matched = torch.logical_not(torch.all(reg_target == 0, dim=-1))
-        num_pos = torch.clamp(reduce_mean(matched.reshape(layers, -1).sum(dim=1).to(torch.float32)), min=1.0)   # (L,)
+        kept = getattr(self, "_sampled", None)
+        if kept and prefix in kept:   # phase 2 of a data-parallel step: the assignment made in positive_counts()
+            cls_target, reg_target, weights, matched, count = kept.pop(prefix)
+        else:
+            cls_target, reg_target, weights, matched, count = self._sample_targets(outs, gt, sampler, reg_weights)
+        num_pos = torch.clamp(reduce_mean(count), min=1.0)   # (L,)
         rows = matched
         if self.cls_threshold_to_reg > 0:
             rows = rows & discrete("cls_gate", cls.max(dim=-1).values.sigmoid() > self.cls_threshold_to_reg)

@@ -64,11 +64,16 @@ class SparseDetector(BaseModule):
         # levels stay in the encoder's dtype (bf16): the depth heads and the flat-layout copy convert on read,
         # so the pyramid is written once in fp32 (as the flat tensor) instead of twice
         levels = [f.reshape((bs, num_cams) + f.shape[1:]) for f in levels]
+
         depths = None
         if return_depth and self.depth_branch is not None:
             depths = self.depth_branch(levels, None if metas is None else metas.get("focal"))
         feature_maps = feature_maps_format(levels, out_dtype=torch.float32)
         feature_maps[0] = shared_feature_grad(feature_maps[0])
+        # cut point of the eager step's two-part backward (hipad_amd.frame.TrainStep); rides on the flat tensor so that it
+        # lives exactly as long as the forward's outputs (a persistent reference on the module kills ROCm 7.2's
+        # capture_end when the step is captured)
+        feature_maps[0]._hipad_levels = levels
         return (feature_maps, depths) if return_depth else feature_maps
 
     def forward(self, img, **data):

@@ -73,3 +73,106 @@ def test_single_process_is_a_noop():
     fg.all_reduce_mean()
     assert torch.equal(before, fg.flat)
     assert D.max_over_ranks(2.5, torch.device("cpu")) == 2.5
+
+
+def _worker_segments_and_counts(rank, world, port, q):
+    """(a) the two-segment all-reduce of FlatGrads, (b) the three-phase positive-count exchange around the losses:
+    every rank evaluates the reference loss on ITS sample with counts averaged over the ranks; the mean of the ranks'
+    loss terms must equal the single-process value on the concatenated batch (what the reference's DDP + reduce_mean
+    computes, sparse_onedecoder.py:1134, 1190, 1292)."""
+    import sys
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    sys.path.insert(0, here)
+    from hipad_amd import dist as D
+    from hipad_amd.compat import count_exchange
+    D.init_from_env("gloo")
+    # (a) segments
+    torch.manual_seed(3)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+    params = list(model.parameters())
+    fg = D.FlatGrads(params)
+    fg.set_split(params[2])
+    model(torch.full((3, 8), float(rank + 1))).sum().backward()
+    fg.check_views()
+    local = fg.flat.clone()
+    fg.all_reduce_mean(segment="early")
+    mid = fg.flat.clone()
+    fg.all_reduce_mean(segment="late")
+    both = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(both, local)
+    expect = torch.stack(both).mean(0)
+    seg_ok = bool(torch.allclose(fg.flat, expect, rtol=1e-6, atol=1e-7)
+                  and torch.equal(mid[fg.split:], local[fg.split:]) and torch.allclose(mid[:fg.split], expect[:fg.split], rtol=1e-6, atol=1e-7))
+    # (b) losses with exchanged counts
+    import loss_case as LC
+    from test_losses import build_criterion
+    crit = build_criterion()
+    outs = LC.head_outputs()
+    data = LC.ground_truth()
+
+    def take(obj, i):
+        if isinstance(obj, torch.Tensor):
+            return obj[i:i + 1]
+        if isinstance(obj, dict):
+            return {k: take(v, i) for k, v in obj.items()}
+        if isinstance(obj, (list, tuple)):
+            return [None if v is None else (take(v, i)) for v in obj]
+        return obj
+
+    mine = [take(o, rank) for o in outs]
+    dmine = {k: (v[rank:rank + 1] if isinstance(v, (list, torch.Tensor)) else v) for k, v in data.items()}
+    count_exchange.begin("collect")
+    crit.positive_counts(*mine, dmine)
+    count_exchange.begin("direct")
+    count_exchange.all_reduce()
+    count_exchange.begin("use")
+    losses = crit.loss(*mine, dmine)
+    count_exchange.begin("direct")
+    keys = sorted(losses)
+    vec = torch.stack([losses[k].detach().double() for k in keys])
+    dist.all_reduce(vec)
+    vec /= world
+    if rank == 0:
+        ref_crit = build_criterion()                      # single process, both samples: local counts, no collective
+        count_exchange.begin("collect")
+        ref_crit.positive_counts(*outs, data)
+        count_exchange.begin("use")
+        whole = ref_crit.loss(*outs, data)
+        count_exchange.begin("direct")
+        ref = torch.stack([whole[k].detach().double() for k in keys])
+        # terms normalised by a positive count are sums / count: the rank mean with a shared count equals the whole-batch
+        # value; terms that are plain means over the batch (ego, plan) agree as well
+        rel = ((vec - ref).abs() / ref.abs().clamp_min(1e-9))
+        q.put((rank, "loss", bool((rel < 2e-5).all()), {k: float(r) for k, r in zip(keys, rel) if r >= 2e-5}))
+    q.put((rank, "segments", seg_ok, {}))
+    dist.destroy_process_group()
+
+
+def test_segment_allreduce_and_count_exchange_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_segments_and_counts, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    results = [q.get(timeout=5) for _ in range(world + 1)]
+    assert all(ok for _, _, ok, _ in results), results
+
+
+def test_reduce_mean_refuses_to_run_inside_a_capture_and_count_exchange_phases():
+    from hipad_amd.compat import CountExchange
+    ex = CountExchange()
+    with pytest.raises(RuntimeError):
+        ex.begin("use")                      # nothing collected yet
+    ex.begin("collect")
+    a = torch.tensor([3.0, 5.0])
+    assert ex.exchange(a) is a and ex.filled == 2
+    ex.begin("use")
+    assert torch.equal(ex.exchange(torch.zeros(2)), a)   # single process: the collected values come back
+    ex.begin("direct")

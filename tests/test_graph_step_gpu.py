@@ -56,3 +56,42 @@ def test_replayed_step_tracks_eager_step():
         assert all(map(lambda v: v == v and abs(v) < 1e6, (le, ge, lg, gg))), (eager, graph)
         assert abs(le - lg) <= 0.03 * abs(le), (eager, graph)      # two eager runs: within 1.1 %
         assert abs(ge - gg) <= 0.30 * abs(ge), (eager, graph)      # two eager runs: within 14 %
+
+
+def test_two_part_backward_equals_one_backward():
+    """The eager step's backward runs in two parts (losses + decoder down to the pyramid levels, then the encoder) so that
+    the decoder's gradient segment can be all-reduced while the encoder's backward runs.  On ONE forward (graph retained)
+    the flat gradient of the two-part path equals the one of a single loss.backward() up to the order of float atomics
+    (two separate forwards of a random-init model differ by ~1 %: near-ties in the target assignment)."""
+    from hipad_amd.frame import SyntheticFrames, TrainStep, build_detector
+    warnings.filterwarnings("ignore")
+    torch.manual_seed(11)
+    model, cfg = build_detector(stage=2, plan_queries=480)
+    model.train()
+    quiet(model)
+    step = TrainStep(model, cfg)
+    img, data = SyntheticFrames(seed=2).next()
+    step.part_forward(img, data, keep_levels=True)
+    levels = [t for t in step._cut if t.requires_grad]
+    assert len(levels) == 4
+    loss = step._objective()
+    g = step.grads
+    g.before_backward()
+    loss.backward(retain_graph=True)
+    g.after_backward()
+    g.check_views()
+    one = g.flat.clone()
+    g.flat.zero_()
+    g.before_backward()
+    torch.autograd.backward([loss], inputs=step._early_params + levels, retain_graph=True)
+    g.after_backward("early")
+    late_before = g.flat[g.split:].clone()
+    torch.autograd.backward(levels, [t.grad for t in levels])
+    g.after_backward("late")
+    g.check_views()
+    two = g.flat
+    assert 0 < g.split < one.numel()
+    assert float(late_before.abs().max()) == 0.0           # nothing of the encoder's segment exists after part one
+    for lo, hi in ((0, g.split), (g.split, one.numel())):
+        rel = float((two[lo:hi] - one[lo:hi]).norm() / one[lo:hi].norm())
+        assert rel < 1e-3, (lo, hi, rel)

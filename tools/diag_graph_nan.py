@@ -19,7 +19,7 @@ for i in range(int(os.environ.get("NSTEPS", "60"))):
     t = time.perf_counter()
     torch.cuda.synchronize()
     step._feed(*frames.next())
-    step.graph_a.replay()
+    step.graph_f.replay(); (step.graph_l.replay() if step.graph_l is not None else None)
     torch.cuda.synchronize()
     flat = step.inner.grads.flat
     pre_bad = [n for n, p in zip(ordered, step.inner.params) if not torch.isfinite(p.grad).all()]

@@ -43,7 +43,7 @@ for k in range(int(os.environ.get("NSTEPS", "8"))):
     if not HOLD:
         del held
     step._feed(*frames.next())
-    step.graph_a.replay()
+    step.graph_f.replay(); (step.graph_l.replay() if step.graph_l is not None else None)
     torch.cuda.synchronize()
     flat = step.inner.grads.flat
     nbad_a = int((~torch.isfinite(flat)).sum())

@@ -1,14 +1,16 @@
 """Top kernels of the last `window_ms` of a rocprofv3 kernel trace by LAUNCH COUNT, with typical grid sizes."""
-import collections, csv, glob, sys
-f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
-window = float(sys.argv[2]) * 1e6
-steps = float(sys.argv[3])
-rows = []
-with open(f) as fh:
-    for r in csv.DictReader(fh):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))))
-end = max(r[1] for r in rows)
-sel = [r for r in rows if r[0] >= end - window]
+import collections, csv, glob, os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _trace
+# usage: trace_counts.py <dir> <window_ms> <steps> [top]   or   trace_counts.py <dir> steps <n> [top]
+rows = _trace.load(sys.argv[1])
+if sys.argv[2] == "steps":
+    sel, steps, _ = _trace.steady_steps(rows, int(sys.argv[3]))
+else:
+    window = float(sys.argv[2]) * 1e6
+    steps = float(sys.argv[3])
+    end = max(r[1] for r in rows)
+    sel = [r for r in rows if r[0] >= end - window]
 agg = collections.defaultdict(lambda: [0, 0.0, collections.Counter()])
 for s, e, n, g in sel:
     k = n.replace("(anonymous namespace)::", "").replace("at::native::", "").replace("void ", "")
