@@ -46,7 +46,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="stage2_full", choices=("stage2_full", "daf_stage2", "stage2_infer"))
+    ap.add_argument("--workload", default="stage2_full",
+                    choices=("stage2_full", "daf_stage2", "stage2_infer", "stage2_r101_1600", "stage1_fp32"))
     ap.add_argument("--plan-queries", type=int, default=480, choices=(48, 480))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch the step kernel by kernel instead of replaying hipGraphs")
@@ -72,18 +73,18 @@ class DafStage2:
 
     LAYERS = 6
 
-    def __init__(self, device, seed, plan_queries=480):
+    def __init__(self, device, seed, plan_queries=480, hw=(256, 704)):
         from hipad_amd import lib, synthetic as syn
         self.lib = lib
         lib.load()
         g = torch.Generator().manual_seed(seed)
-        ss, st, F = syn.pyramid_tables((256, 704))
+        ss, st, F = syn.pyramid_tables(hw)
         self.F = F
         self.ss = torch.from_numpy(ss).to(device)
         self.st = torch.from_numpy(st).to(device)
         self.feat = torch.randn(1, F, 256, generator=g).to(device)
         self.gfeat = torch.zeros_like(self.feat)
-        pm, wh = syn.projection_mats((256, 704))
+        pm, wh = syn.projection_mats(hw)
         names = ["det", "map", "plan" if plan_queries == 480 else "plan48", "ego"]
         self.calls = []
         self.host = {}
@@ -197,14 +198,15 @@ class DafStage2:
 class Stage2Full:
     """One training step of the whole model per frame (see module docstring)."""
 
-    def __init__(self, device, seed, plan_queries=480, bs=1, eager=False):
+    def __init__(self, device, seed, plan_queries=480, bs=1, eager=False, hw=(256, 704), stage=2, **build):
         import warnings
         warnings.filterwarnings("ignore", category=DeprecationWarning)
         from hipad_amd.frame import GraphedTrainStep, SyntheticFrames, TrainStep, build_detector
         torch.manual_seed(1234)  # identical initial weights on every rank (then broadcast anyway)
-        self.model, self.cfg = build_detector(stage=2, input_hw=(256, 704), plan_queries=plan_queries, device=device)
+        self.model, self.cfg = build_detector(stage=stage, input_hw=hw, plan_queries=plan_queries, device=device, **build)
         self.model.train()
-        self.frames = SyntheticFrames(bs=bs, input_hw=(256, 704), device=device, seed=seed)
+        self.frames = SyntheticFrames(bs=bs, input_hw=hw, device=device, seed=seed)
+        self.hw, self.stage = hw, stage
         self.bs, self.plan_queries, self.eager = bs, plan_queries, eager
         if eager:
             self.train_step = TrainStep(self.model, self.cfg)
@@ -212,7 +214,7 @@ class Stage2Full:
         else:
             self.graphed = GraphedTrainStep(self.model, self.cfg, self.frames)  # warms up (cold frames) + captures
             self.train_step = self.graphed.inner
-        self.daf = DafStage2(device, seed, plan_queries)  # op-level harness for the roofline / cpu legs
+        self.daf = DafStage2(device, seed, plan_queries, hw=hw)  # op-level harness for the roofline / cpu legs
 
     def step(self):
         if self.graphed is not None:
@@ -235,6 +237,7 @@ class Stage2Full:
             self.model.head.onedecoder_head.run_step = was
         return {k: round(float(v), 4) for k, v in losses.items()}
 
+
     def frame_roofline(self, measured_ms_per_frame):
         """roofline.frame of the JSON line (hipad_amd.roofline): one extra eager forward with per-operator accounting."""
         from hipad_amd import roofline as RL
@@ -255,6 +258,8 @@ class Stage2Full:
         modules on CPU tensors with oracle/ supplying the operators that exist only as HIP kernels (oracle/cpu_frame.py);
         all host cores, count stated."""
         from oracle import cpu_frame
+        if self.stage != 2 or tuple(self.hw) != (256, 704):
+            return None   # the CPU baseline is quoted on the headline configuration only
         r = cpu_frame.time_frames(seconds=seconds, plan_queries=self.plan_queries)
         return dict(value=round(r["frames"] / r["seconds"], 4), unit="frames/s", cores=r["cores"], kind="port",
                     sample=f"{r['frames']} whole stage-2 training frame(s) (ResNet50+FPN + decoder + losses, forward + "
@@ -400,9 +405,14 @@ def main():
         raise SystemExit(f"bench: --gpus {a.gpus} but the launcher started {world} rank(s); refusing to report "
                          f"a {world}-rank number as the {a.gpus}-GPU point")
     dev = torch.device("cuda", local)
-    full = a.workload == "stage2_full"
+    full = a.workload in ("stage2_full", "stage2_r101_1600", "stage1_fp32")
     infer = a.workload == "stage2_infer"
-    wl = (Stage2Full(dev, seed=rank, plan_queries=a.plan_queries, bs=a.bs, eager=a.eager) if full
+    extra = {}
+    if a.workload == "stage2_r101_1600":   # BASELINE.json config 5: the pyramid (522 MB fp32) leaves the Infinity Cache
+        extra = dict(hw=(640, 1600), backbone_depth=101)
+    elif a.workload == "stage1_fp32":      # BASELINE.json config 2
+        extra = dict(stage=1, encoder_dtype=torch.float32)
+    wl = (Stage2Full(dev, seed=rank, plan_queries=a.plan_queries, bs=a.bs, eager=a.eager, **extra) if full
           else Stage2Infer(dev, seed=rank, plan_queries=a.plan_queries) if infer
           else DafStage2(dev, seed=rank, plan_queries=a.plan_queries))
 
@@ -437,14 +447,21 @@ def main():
         roof["frame"] = wl.frame_roofline(dt / a.steps * 1e3 / a.bs)
         note("frame roofline census done")
     if full:
-        workload = ("stage2_full: one training step (forward + the reference's losses with device-side Hungarian target "
+        hw_txt = "%dx%d" % (wl.hw[1], wl.hw[0])
+        enc_txt = {"stage2_full": "ResNet50+FPN bf16 channels-last", "stage2_r101_1600": "ResNet101+FPN bf16 channels-last "
+                   "(BASELINE config 5: 510 000 pyramid positions, 522 MB fp32, outside the Infinity Cache)",
+                   "stage1_fp32": "ResNet50+FPN fp32 (BASELINE config 2: hipad_b2d_stage1, no motion head)"}[a.workload]
+        workload = (f"{a.workload}: one training step (forward + the reference's losses with device-side Hungarian target "
                     "assignment [det/map/motion/ego/plan/depth terms] + backward + grad all-reduce + clip + AdamW) of "
-                    "hipad_b2d_stage2 on one 6-cam 704x256 frame per GPU: ResNet50+FPN bf16 channels-last, decoder det 900 "
+                    f"hipad_b2d_stage{wl.stage} on one 6-cam {hw_txt} frame per GPU: {enc_txt}, decoder det 900 "
                     f"+ map 100 + plan {a.plan_queries} + ego 1 queries x 6 layers + motion head, bf16 GEMMs / bf16-operand "
                     "attention, fp32 aggregation; synthetic ground truth (~20 boxes, ~10 map lines per frame)")
-        dtype = "bf16"
+        dtype = "f32" if a.workload == "stage1_fp32" else "bf16"
         cfg = dict(workload=workload, frames_per_gpu_per_step=a.bs, plan_queries=a.plan_queries, parallelism=f"dp{world}",
-                   launch="eager" if a.eager else "hipGraph replay (fwd+bwd graph, eager RCCL all-reduce, clip+AdamW graph)",
+                   launch="eager (decoder-segment all-reduce overlapped with the encoder's backward)" if a.eager else
+                   ("hipGraph replay: forward+losses+backward graph, clip+AdamW graph" if world == 1 else
+                    "hipGraph replay: forward graph | positive-count all-reduce | losses+backward graph | flat-gradient "
+                    "all-reduce (RCCL) | clip+AdamW graph"),
                    with_cp=False, with_cp_note="activation checkpointing of the backbone (reference config: with_cp=True, "
                    "projects/configs/hipad_b2d_stage2.py:119) is OFF: 288 GB of HBM hold the activations, so the "
                    "reference's backbone re-computation in the backward is not part of this step",

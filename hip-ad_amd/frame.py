@@ -13,7 +13,8 @@ import torch
 from . import synthetic as syn
 
 
-def build_detector(stage=2, input_hw=(256, 704), plan_queries=None, device="cuda", with_cp=False):
+def build_detector(stage=2, input_hw=(256, 704), plan_queries=None, device="cuda", with_cp=False, backbone_depth=None,
+                   encoder_dtype=None):
     import projects.mmdet3d_plugin.models  # noqa: F401  registers the modules
     # MIOpen exhaustive find on the first call of every convolution shape (during the eager warm-up frames):
     # the step is 5.4 ms faster than with the default quick find (63.1 -> 57.7 ms).  Immediate mode
@@ -26,6 +27,10 @@ def build_detector(stage=2, input_hw=(256, 704), plan_queries=None, device="cuda
     model_cfg = cfg["model"]
     model_cfg["img_backbone"]["pretrained"] = None  # no network / checkpoints here: random init
     model_cfg["img_backbone"]["with_cp"] = with_cp
+    if backbone_depth is not None:      # BASELINE.json config 5: ResNet101
+        model_cfg["img_backbone"]["depth"] = backbone_depth
+    if encoder_dtype is not None:       # BASELINE.json config 2: fp32 encoder
+        model_cfg["encoder_dtype"] = encoder_dtype
     if plan_queries == 48 and stage == 2:
         # BASELINE.json words the plan set as 6x8 = 48 queries: keep one anchor group of the ten
         od = model_cfg["head"]["onedecoder_head"]

@@ -1,0 +1,87 @@
+"""BASELINE.json configurations 2 and 5 on one GPU.
+
+  config 2: hipad_b2d_stage1, ResNet50, 6 cams 704x256, 900 det queries, bs 1, fp32 encoder
+  config 5: hipad_b2d_stage2 with a ResNet101 backbone at 6 cams 1600x640, 4 FPN levels: the pyramid has 510 000
+            positions per sample (522 MB fp32): it no longer fits the 256 MiB Infinity Cache, the gather is HBM-bound.
+
+For each: the aggregation operator's size-independent properties on that pyramid (Euler identities tying backward to
+forward, linearity, determinism, sorted-vs-atomic feature gradient) and finite training steps of the whole model."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-12))
+
+
+def projected_inputs(hw, name, seed):
+    """Aggregation inputs of a query set (det / map / plan) on the pyramid of input size ``hw``: key points projected
+    through the Bench2Drive camera rig (the frame's real geometry: ~1 of 6 cameras sees a point)."""
+    from hipad_amd import synthetic as syn
+    g = torch.Generator().manual_seed(seed)
+    ss, st, F = syn.pyramid_tables(hw)
+    pm, wh = syn.projection_mats(hw)
+    loc = torch.from_numpy(syn.project(syn.synthetic_key_points(name, seed=seed), pm, wh)).contiguous()
+    A, P = loc.shape[1:3]
+    feat = torch.randn(1, F, 256, generator=g)
+    w = torch.softmax(torch.randn(1, A, P * 6 * 4, 8, generator=g), 2).reshape(1, A, P, 6, 4, 8).contiguous()
+    gout = torch.randn(1, A, 256, generator=g)
+    return [t.cuda() for t in (feat, torch.from_numpy(ss), torch.from_numpy(st), loc, w, gout)], F
+
+
+@pytest.mark.parametrize("hw,name,F_expected", [((256, 704), "det", 89760), ((640, 1600), "det", 510000),
+                                                 ((640, 1600), "map", 510000), ((640, 1600), "plan", 510000)])
+def test_aggregation_properties_on_the_config_pyramids(hw, name, F_expected):
+    from hipad_amd import lib
+    d, F = projected_inputs(hw, name, seed=5)
+    assert F == F_expected
+    out = lib.daf_forward(*d[:5])
+    assert torch.equal(out, lib.daf_forward(*d[:5]))                      # no atomics in the forward: bitwise reproducible
+    assert torch.count_nonzero(lib.daf_forward(d[0], d[1], d[2], d[3], torch.zeros_like(d[4]))) == 0
+    assert rel_err(lib.daf_forward(d[0], d[1], d[2], d[3], (2.5 * d[4]).contiguous()), 2.5 * out) < 1e-5
+    gf = torch.zeros_like(d[0]); gl = torch.empty_like(d[3]); gw = torch.empty_like(d[4])
+    lib.daf_backward(*d, gf, gl, gw, overwrite_loc_w=True)
+    rhs = float((out.double() * d[5].double()).sum())
+    assert abs(float((gw.double() * d[4].double()).sum()) - rhs) < 1e-4 * max(1.0, abs(rhs))   # out is linear in w
+    assert abs(float((gf.double() * d[0].double()).sum()) - rhs) < 1e-4 * max(1.0, abs(rhs))   # ... and in feat
+    gf2 = torch.zeros_like(d[0]); gl2 = torch.empty_like(d[3]); gw2 = torch.empty_like(d[4])
+    lib.daf_backward(*d, gf2, gl2, gw2, overwrite_loc_w=True, atomic_feat=True)               # the atomic-scatter variant
+    assert rel_err(gf2, gf) < 1e-5 and rel_err(gw2, gw) < 1e-5 and rel_err(gl2, gl) < 1e-4
+    valid, taps = lib.daf_taps(d[1], d[2], d[3], F)
+    assert int(valid.sum()) > 0 and int(taps[..., 3].max()) < F
+
+
+def finite_steps(stage, hw, steps=2, **build):
+    from hipad_amd.frame import SyntheticFrames, TrainStep, build_detector
+    warnings.filterwarnings("ignore")
+    torch.manual_seed(3)
+    model, cfg = build_detector(stage=stage, input_hw=hw, **build)
+    torch.backends.cudnn.benchmark = False   # two steps only: skip MIOpen's exhaustive search of the new convolution shapes
+    model.train()
+    frames = SyntheticFrames(bs=1, input_hw=hw, seed=1)
+    step = TrainStep(model, cfg)
+    out = []
+    for _ in range(steps):
+        loss = step(*frames.next())
+        out.append((float(loss), float(step.grad_norm)))
+    return model, out
+
+
+def test_config2_stage1_resnet50_fp32_trains():
+    model, trace = finite_steps(1, (256, 704), encoder_dtype=torch.float32)
+    dec = model.head.onedecoder_head
+    assert model.encoder_dtype == torch.float32 and dec.num_det_anchor == 900
+    assert all(np.isfinite(v) and abs(v) < 1e6 for pair in trace for v in pair), trace
+
+
+def test_config5_stage2_resnet101_1600x640_trains():
+    model, trace = finite_steps(2, (640, 1600), backbone_depth=101)
+    assert model.img_backbone.depth == 101
+    dec = model.head.onedecoder_head
+    assert dec.total_num_anchor == 1481
+    assert all(np.isfinite(v) and abs(v) < 1e6 for pair in trace for v in pair), trace

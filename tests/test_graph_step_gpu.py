@@ -92,6 +92,9 @@ def test_two_part_backward_equals_one_backward():
     two = g.flat
     assert 0 < g.split < one.numel()
     assert float(late_before.abs().max()) == 0.0           # nothing of the encoder's segment exists after part one
-    for lo, hi in ((0, g.split), (g.split, one.numel())):
+    # decoder segment: same arithmetic, only the order of float atomics differs.  Encoder segment: the gradient handed
+    # over at the cut point is a bf16 tensor (the encoder runs under bf16 autocast) summed from its consumers in a
+    # different order -- bf16 rounding (eps 4e-3) of the hand-off, measured 3.8e-3
+    for (lo, hi), tol in (((0, g.split), 1e-3), ((g.split, one.numel()), 1e-2)):
         rel = float((two[lo:hi] - one[lo:hi]).norm() / one[lo:hi].norm())
-        assert rel < 1e-3, (lo, hi, rel)
+        assert rel < tol, (lo, hi, rel)
