@@ -1,11 +1,14 @@
 """One training frame of the whole hot path on synthetic data: multi-view images -> ResNet/FPN ->
 unified decoder -> objective -> backward -> optimiser step.  Shared by bench.py, smoke() and tests.
 
-The objective is a SURROGATE (mean square of every head output + the depth maps): the reference's
-target assignment and losses (sparse_onedecoder.py:1094-1579) are the first "next" row of SURVEY.md
-section 8f and not built yet.  It touches every head, so the backward runs through every kernel and
-every parameter the real losses would reach; the only work it leaves out is the loss arithmetic itself
-(and its host-side Hungarian matching).
+The objective is the reference's: every det / map / motion / ego / plan loss term with Hungarian target
+assignment on the device (projects/mmdet3d_plugin/models/criterion.py; reference sparse_onedecoder.py:1094-1579)
+plus the dense-depth loss.  (``OBJECTIVE = "surrogate"`` -- mean square of every head output -- remains as a
+debugging aid that skips the target assignment.)
+
+The step exists in two forms: ``TrainStep`` launches it eagerly in three parts (forward | losses + decoder
+backward | encoder backward) and overlaps the all-reduce of the decoder's gradient segment with the encoder's
+backward; ``GraphedTrainStep`` replays it from hipGraphs (the collectives sit between the graphs).
 """
 import numpy as np
 import torch

@@ -77,3 +77,32 @@ def test_taps_index_work(golden):
         hl = int(np.floor(np.float32(np.float32(loc[b, a, p, c, 1]) * np.float32(h)) - np.float32(0.5)))
         wl = int(np.floor(np.float32(np.float32(loc[b, a, p, c, 0]) * np.float32(w_)) - np.float32(0.5)))
         assert taps[b, a, p, c, s, 0] == hl and taps[b, a, p, c, s, 1] == wl
+
+
+def test_threaded_oracle_is_bitwise_the_sequential_one():
+    """bench.py's cpu_baseline deals anchors to several host threads (oracle/daf.py set_threads); the results must be
+    bit for bit the one-thread checker's: an anchor's output row is summed by one thread in the sequential order, and the
+    feature-gradient scatter is partitioned by pyramid row, each row receiving its addends in the sequential order."""
+    import numpy as np
+    from oracle import daf as O
+    rng = np.random.default_rng(3)
+    cams, A, P = 3, 41, 7
+    shapes = [(8, 22), (4, 11)]
+    ss = np.array([shapes] * cams, np.int32)
+    sizes = (ss[..., 0] * ss[..., 1]).reshape(-1)
+    st = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int32).reshape(cams, -1)
+    feat = rng.standard_normal((2, int(sizes.sum()), 64), dtype=np.float32)
+    loc = rng.random((2, A, P, cams, 2), dtype=np.float32) * 1.4 - 0.2
+    w = rng.random((2, A, P, cams, 2, 8), dtype=np.float32)
+    go = rng.standard_normal((2, A, 64), dtype=np.float32)
+    try:
+        O.set_threads(1)
+        ref = (O.daf_forward(feat, ss, st, loc, w),) + tuple(O.daf_backward(feat, ss, st, loc, w, go))
+        ref64 = O.daf_backward(feat, ss, st, loc, w, go, acc64=True)
+        O.set_threads(4)
+        got = (O.daf_forward(feat, ss, st, loc, w),) + tuple(O.daf_backward(feat, ss, st, loc, w, go))
+        got64 = O.daf_backward(feat, ss, st, loc, w, go, acc64=True)
+    finally:
+        O.set_threads(1)
+    assert all(np.array_equal(a, b) for a, b in zip(ref, got))
+    assert all(np.array_equal(a, b) for a, b in zip(ref64, got64))
