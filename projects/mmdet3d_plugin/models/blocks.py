@@ -119,7 +119,9 @@ class DeformableFeatureAggregation(BaseModule):
         keep = self._keep_mask(bs, num_anchor, feature.device)
         if self.camera_encoder is not None:
             cam_in = metas["projection_mat"][:, :, :3].reshape(bs, self.num_cams, -1)
-            cam_embed = self.camera_encoder(cam_in.to(feature.dtype))
+            cam_embed = getattr(self, "_cam_embed", None)     # precomputed for the whole frame by the decoder (one launch
+            if cam_embed is None:                              # for all modules' camera encoders), else computed here
+                cam_embed = self.camera_encoder(cam_in.to(feature.dtype))
             u = self.weights_fc(feature)                       # (bs, A, n): anchor part + bias
             v = HF.linear(cam_embed, self.weights_fc.weight)   # (bs, cams, n): camera part
             w = HF.sampling_weights(u, v, keep, L, P, G)

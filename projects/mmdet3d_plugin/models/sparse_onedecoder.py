@@ -320,6 +320,40 @@ class SparseOneDecoder(DecoderLoss, BaseModule):
                                            prediction.detach().float().contiguous(), self.motion_anchor.detach(), freq,
                                            SIN_YAW, COS_YAW)
 
+    def _frame_constants(self, metas, batch_size):
+        """Everything that depends only on the frame's meta data and on parameters, evaluated ONCE per forward instead
+        of once per decoder layer (the reference recomputes them in every layer with identical inputs: the values are
+        the same, the gradients of the shared encoders arrive as a sum either way):
+          * the target-point and command embeddings added to the plan queries' anchor embedding in every refine step
+            (reference sparse_onedecoder.py:984-1003);
+          * the camera embeddings of all DeformableFeatureAggregation modules (reference blocks.py:187-190) -- on the GPU
+            as ONE grouped chain launch for the 24 modules' camera encoders."""
+        self._tp_embed = self._cmd_embed = None
+        if "plan" in self.task_select:
+            if self.with_target_point_embed:
+                tp = metas["target_point"].unsqueeze(1).unsqueeze(1)
+                self._tp_embed = self.target_point_encoder(gen_sineembed_for_position(tp)).squeeze(1)
+            if self.with_command_embed:
+                cmd = metas["gt_ego_fut_cmd"].unsqueeze(1).unsqueeze(1)
+                self._cmd_embed = self.command_embed_encoder(cmd).squeeze(1)
+        mods = [m for n in self.query_select for m in getattr(self, f"{n}_deformable", [])
+                if getattr(m, "camera_encoder", None) is not None]
+        for m in mods:
+            m._cam_embed = None
+        pm = metas.get("projection_mat")
+        if not mods or pm is None or not pm.is_cuda:
+            return
+        from hipad_amd import chain as CH
+        if not CH.usable(pm):
+            return
+        specs = [CH.spec_of(m.camera_encoder) for m in mods]
+        if any(sp is None for sp in specs):
+            return
+        cam_in = pm[:, :, :3].reshape(batch_size, pm.shape[1], -1).float()
+        outs = CH.run([CH.Call(sp, cam_in) for sp in specs])
+        for m, o in zip(mods, outs):
+            m._cam_embed = o
+
     def _open_branches(self, batch_size, metas, feature_maps, bank_idx):
         br = {}
         for name in self.query_select:
@@ -393,6 +427,7 @@ class SparseOneDecoder(DecoderLoss, BaseModule):
             self._probe(slot, op, state)
 
         probe(-1, "open")
+        self._frame_constants(metas, batch_size)
         for slot, (op, layer) in enumerate(zip(self.operation_order, self.layers)):
             if layer is None:
                 continue
@@ -479,11 +514,9 @@ class SparseOneDecoder(DecoderLoss, BaseModule):
                     p = br["plan"]
                     embed = p.embed
                     if self.with_target_point_embed:
-                        tp = metas["target_point"].unsqueeze(1).unsqueeze(1)
-                        embed = embed + self.target_point_encoder(gen_sineembed_for_position(tp)).squeeze(1)
+                        embed = embed + self._tp_embed
                     if self.with_command_embed:
-                        cmd = metas["gt_ego_fut_cmd"].unsqueeze(1).unsqueeze(1)
-                        embed = embed + self.command_embed_encoder(cmd).squeeze(1)
+                        embed = embed + self._cmd_embed
                     if self.with_ego_instance_feature:
                         p.feature = p.feature + br["ego"].feature
                         embed = embed + br["ego"].embed
@@ -531,6 +564,10 @@ class SparseOneDecoder(DecoderLoss, BaseModule):
             det_output["instance_id"] = br["det"].bank.get_instance_id(det_cls, br["det"].anchor,
                                                                        self.det_decoder.score_threshold)
         self.run_step += 1
+        for n in self.query_select:   # the per-frame camera embeddings must not outlive the forward
+            for m in getattr(self, f"{n}_deformable", []):
+                m._cam_embed = None
+        self._tp_embed = self._cmd_embed = None
         return det_output, map_output, ego_output, plan_output, motion_output, scenes_output
 
     # ------------------------------------------------------------------------------------
