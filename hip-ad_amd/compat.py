@@ -34,6 +34,8 @@ class LayerNorm(nn.LayerNorm):
         from . import functional as HF
         if x.is_cuda and len(self.normalized_shape) == 1 and self.weight is not None:
             return HF.layer_norm(x, self.weight, self.bias, self.eps)
+        if x.is_cuda:
+            HF._library("LayerNorm module (normalized_shape %s, affine %s)" % (tuple(self.normalized_shape), self.weight is not None))
         return super().forward(x)
 
 
@@ -99,6 +101,7 @@ if not HAVE_MMCV:
     BBOX_CODERS = _registry("bbox coder")
     BACKBONES = _registry("backbone")
     NECKS = _registry("neck")
+    PIPELINES = _registry("pipeline")
 
     NORM_LAYERS.register_module("LN", module=LayerNorm)
 
@@ -142,6 +145,7 @@ if not HAVE_MMCV:
             nn.Sequential.__init__(self, *mods)
 else:
     from mmdet.models import BACKBONES, NECKS  # type: ignore  # noqa: F401
+    from mmdet.datasets.builder import PIPELINES  # type: ignore  # noqa: F401
 
 
 class Linear(nn.Linear):
@@ -155,6 +159,8 @@ class Linear(nn.Linear):
         from . import functional as HF
         if x.is_cuda and HF.LINEAR_MODE == "mfma_bf16":
             return HF.linear(x, self.weight, self.bias, relu=self.fuse_relu)
+        if x.is_cuda:
+            HF._library("Linear module (mode %s)" % HF.LINEAR_MODE)
         y = nn.functional.linear(x, self.weight, self.bias)
         return nn.functional.relu(y) if self.fuse_relu else y
 

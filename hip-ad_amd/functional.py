@@ -131,6 +131,19 @@ LINEAR_BWD = _os.environ.get("HIPAD_LINEAR_BWD", "mfma")  # "torch": debugging a
 # LayerNorm weights and biases): hipad_amd.dist.FlatGrads uses it to tell them from the parameters autograd
 # accumulates itself (see FlatGrads.loosen)
 INPLACE_PARAMS = set()
+# Every time a GPU tensor is handed to a torch / library implementation instead of a kernel of this package it is
+# counted here by reason -- in the default (mfma_bf16) mode a training frame must leave this empty
+# (tests/test_graph_step_gpu.py); HIPAD_STRICT=1 turns such a call into an error.  CPU tensors (host-logic tests, the
+# oracle's CPU frame) are not kernels' business and are not counted.
+import collections as _collections
+LIBRARY_CALLS = _collections.Counter()
+STRICT = _os.environ.get("HIPAD_STRICT", "0") == "1"
+
+
+def _library(reason):
+    LIBRARY_CALLS[reason] += 1
+    if STRICT:
+        raise RuntimeError("hipad_amd: %s would run on a torch / library kernel (HIPAD_STRICT=1)" % reason)
 
 
 class linear_mode:
@@ -219,6 +232,8 @@ def linear(x, weight, bias=None, relu=False, rows=None):
     parameter's gradient buffer."""
     r0, r1 = (0, weight.shape[0]) if rows is None else rows
     if not (x.is_cuda and LINEAR_MODE == "mfma_bf16"):
+        if x.is_cuda:
+            _library("linear (mode %s)" % LINEAR_MODE)
         y = torch.nn.functional.linear(x, weight[r0:r1], None if bias is None else bias[r0:r1])
         return torch.relu(y) if relu else y
     return _Linear.apply(x, weight, bias, bool(relu), int(r0), int(r1))
@@ -271,6 +286,8 @@ def layer_norm(x, weight, bias, eps=1e-5):
     tests) and shapes off the kernel's range go through torch."""
     n = x.shape[-1]
     if not x.is_cuda or n % 4 or n > 1024 or x.dtype != torch.float32:
+        if x.is_cuda:
+            _library("layer_norm (n = %d, %s)" % (n, x.dtype))
         return torch.nn.functional.layer_norm(x, (n,), weight, bias, eps)
     return _LayerNorm.apply(x, weight, bias, float(eps))
 

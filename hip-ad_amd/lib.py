@@ -46,6 +46,11 @@ SIGNATURES = {
     "hipad_lr_factor": (ctypes.c_float, [c_void_p, c_int]),
     "hipad_keep_mask": (c_int, [c_void_p, ctypes.c_longlong, ctypes.c_float, ctypes.c_uint, c_void_p, c_void_p]),
     "hipad_chunk_mix": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "hipad_resample_tables": (c_int, [c_int, c_int, c_void_p, c_void_p]),
+    "hipad_rotate_fixed": (c_int, [ctypes.c_double, c_int, c_int, c_void_p]),
+    "hipad_image_resize_rows": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
+    "hipad_image_finish": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                                                      c_void_p]),
     "hipad_motion_query_embed": (c_int, [c_void_p] * 5 + [ctypes.c_longlong] + [c_int] * 7 + [c_void_p]),
     "hipad_chain_forward": (c_int, [c_void_p, c_int, c_void_p]),
     "hipad_chain_debug_stamps": (None, [c_void_p]),

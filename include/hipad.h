@@ -435,6 +435,40 @@ int hipad_motion_query_embed(float *out, const float *cls, const float *box, con
                              long long n_anchor, int num_classes, int box_dim, int sin_col, int cos_col, int modes,
                              int steps, int half_dim, hipad_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Image leg of the training data pipeline (hip-ad_amd/csrc/imgpipe.hip).  Replaces, for all camera images of one
+ * sample and with the frames already in HBM as uint8 (n_img, src_h, src_w, 3):
+ *   datasets/pipelines/augment.py:46-68      ResizeCropFlipImage._img_transform (PIL resize [bicubic] -> crop ->
+ *                                            FLIP_LEFT_RIGHT -> rotate [nearest] -> float32)
+ *   datasets/pipelines/transform.py:286-321  NormalizeMultiviewImage (mmcv.imnormalize)
+ *   datasets/pipelines/transform.py:136-138  the HWC -> CHW transpose + stack of NuScenesSparse4DAdaptor
+ * Geometry is bit-exact with Pillow (tests/test_imgpipe_*.py).  Host-side table builders (no GPU needed):
+ *   hipad_resample_tables  Pillow's tap tables for resizing in_size -> out_size with the bicubic filter: bounds
+ *                          (out_size, 2) = [first source index, tap count], coeffs (out_size, ksize) with 22 fractional
+ *                          bits; returns ksize (> 0; call with NULL tables to size the buffers) or a negative status.
+ *                          in_size == out_size gives identity taps (Pillow skips that pass).
+ *   hipad_rotate_fixed     Image.rotate(angle_deg)'s inverse map about (width / 2, height / 2) as the six 16.16 fixed
+ *                          point numbers Pillow's affine_fixed walks; returns 1 (a_out filled), 0 (angle % 360 == 0: the
+ *                          copy path, nothing to apply) or a negative status (180 / 90 / 270 transpose paths, overflow).
+ * Device entries:
+ *   hipad_image_resize_rows  horizontal pass of source rows [row0, row0 + rows) -> tmp (n_img, rows, out_w, 3) uint8.
+ *   hipad_image_finish       per output pixel: inverse rotate -> flip -> crop -> vertical pass on tmp -> [BGR->RGB]
+ *                            -> [(v - mean) * (1 / std)] -> out[n * s[0] + c * s[1] + y * s[2] + x * s[3]] (element
+ *                            strides: CHW fp32, HWC or channels-last).  bounds_v's first indices are relative to tmp's
+ *                            first row (row0 already subtracted); crop_box = (x0, y0, x1, y1) in the resized image, zero
+ *                            fill outside; rotate_a = the six numbers of hipad_rotate_fixed or NULL; mean / std both
+ *                            NULL = raw float32 pixel values (ResizeCropFlipImage alone).
+ * ---------------------------------------------------------------------------------- */
+int hipad_resample_tables(int in_size, int out_size, int *bounds, int *coeffs);
+int hipad_rotate_fixed(double angle_deg, int width, int height, int *a_out);
+int hipad_image_resize_rows(unsigned char *tmp, const unsigned char *src, const int *bounds_h, const int *coeffs_h,
+                            int ksize_h, int n_img, int src_h, int src_w, int row0, int rows, int out_w,
+                            hipad_stream_t stream);
+int hipad_image_finish(float *out, const long long *out_strides, const unsigned char *tmp, const int *bounds_v,
+                       const int *coeffs_v, int ksize_v, int n_img, int tmp_rows, int resized_w, int resized_h,
+                       const int *crop_box, int flip, const int *rotate_a, const float *mean, const float *std, int to_rgb,
+                       hipad_stream_t stream);
+
 /* Tuning knob (host side, process-wide): target number of (point, camera) pairs one
  * wavefront owns in the forward / backward kernels.  <=0 restores the default. */
 void hipad_daf_set_pairs_per_wave(int fwd, int bwd);

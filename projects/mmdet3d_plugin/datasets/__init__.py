@@ -1,0 +1,14 @@
+"""Data-pipeline side of the hot path: the image leg on the device and the host logic
+that feeds it.  Same module and class names as the reference's ``projects.mmdet3d_plugin.datasets`` for what is built:
+
+  pipelines.ResizeCropFlipImage, pipelines.NormalizeMultiviewImage   (device kernels when handed device tensors)
+  pipelines.DeviceImageTransform (ours)                              the two above + HWC->CHW in two launches
+  samplers.GroupInBatchSampler                                       sequence-grouped infinite sampler (host logic)
+  augmentation.get_augmentation                                      Bench2DriveDataset.get_augmentation
+
+Not built (out of section 8's scope): file loading / JPEG decode, the annotation database, map vectorisation, lidar
+depth maps, PhotoMetricDistortionMultiViewImage (cv2 colour-space arithmetic) and the evaluation code.
+"""
+from .pipelines import *  # noqa: F401,F403
+from .samplers import *  # noqa: F401,F403
+from .augmentation import get_augmentation  # noqa: F401

@@ -1,0 +1,69 @@
+"""``NormalizeMultiviewImage`` (reference datasets/pipelines/transform.py:286-321) on device tensors, and
+``DeviceImageTransform`` (ours): ResizeCropFlipImage + NormalizeMultiviewImage + the HWC->CHW stack of
+NuScenesSparse4DAdaptor (transform.py:136-138) and its projection_mat / image_wh entries (:112-116) as ONE pipeline
+step = two kernel launches per sample, for pipelines with nothing between the resize and the normalisation."""
+import numpy as np
+import torch
+
+from hipad_amd import imgpipe
+from hipad_amd.compat import PIPELINES
+
+__all__ = ["NormalizeMultiviewImage", "DeviceImageTransform"]
+
+
+@PIPELINES.register_module()
+class NormalizeMultiviewImage(object):
+    """(x[BGR->RGB] - mean) * (1 / std) in float32, mmcv.imnormalize's arithmetic, on (h, w, 3) device tensors."""
+
+    def __init__(self, mean, std, to_rgb=True):
+        self.mean = np.array(mean, dtype=np.float32)
+        self.std = np.array(std, dtype=np.float32)
+        self.to_rgb = to_rgb
+
+    def __call__(self, results):
+        imgs = results["img"]
+        x = imgs if isinstance(imgs, torch.Tensor) else torch.stack(list(imgs), 0)
+        x = x.float()
+        if self.to_rgb:
+            x = x.flip(-1)
+        mean = torch.from_numpy(self.mean).to(x.device)
+        stdinv = torch.from_numpy((1.0 / self.std.astype(np.float64)).astype(np.float32)).to(x.device)
+        x = (x - mean) * stdinv
+        results["img"] = list(x.unbind(0))
+        results["img_norm_cfg"] = dict(mean=self.mean, std=self.std, to_rgb=self.to_rgb)
+        return results
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}(mean={self.mean}, std={self.std}, to_rgb={self.to_rgb})"
+
+
+@PIPELINES.register_module()
+class DeviceImageTransform(object):
+    def __init__(self, mean, std, to_rgb=True, channels_last=False):
+        self.mean = np.array(mean, dtype=np.float32)
+        self.std = np.array(std, dtype=np.float32)
+        self.to_rgb = to_rgb
+        self.channels_last = channels_last
+
+    def __call__(self, results):
+        src = results["img"] if isinstance(results["img"], torch.Tensor) else torch.stack(list(results["img"]), 0)
+        aug_config = results.get("aug_config") or {}
+        n, H, W = src.shape[:3]
+        img = imgpipe.transform_images(src.contiguous(), aug_config, self.mean, self.std, self.to_rgb, layout="chw",
+                                       channels_last=self.channels_last)
+        if results.get("aug_config") is not None:
+            mat = imgpipe.transform_matrix(aug_config, H, W)
+            for i in range(n):
+                results["lidar2img"][i] = mat @ results["lidar2img"][i]
+                if "ego2img" in results:
+                    results["ego2img"][i] = mat @ results["ego2img"][i]
+                if "cam_intrinsic" in results:
+                    results["cam_intrinsic"][i][:3, :3] *= aug_config["resize"]
+        h, w = img.shape[-2:]
+        results["img"] = img                                            # (n, 3, h, w) float32: what the adaptor stacks
+        results["img_shape"] = [(h, w)] * n
+        results["img_norm_cfg"] = dict(mean=self.mean, std=self.std, to_rgb=self.to_rgb)
+        if "lidar2img" in results:
+            results["projection_mat"] = np.float32(np.stack(results["lidar2img"]))
+            results["image_wh"] = np.ascontiguousarray(np.array(results["img_shape"], dtype=np.float32)[:, :2][:, ::-1])
+        return results

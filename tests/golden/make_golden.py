@@ -16,6 +16,8 @@ tests/golden/_ref_shim.py (third-party names only are stubbed):
   * ..._get_weights, forward                      (models/blocks.py:124-214)
   * SparseBox3DKeyPointsGenerator (models/det/blocks.py:159-224),
     SparsePoint3DKeyPointsGenerator (models/map/blocks.py:137-225)
+  * --only pipeline: ResizeCropFlipImage (datasets/pipelines/augment.py:11-94), Bench2DriveDataset.get_augmentation
+    (datasets/bench2drive_dataset.py:709-751), GroupInBatchSampler (datasets/samplers/group_in_batch_sampler.py:48-178)
 Only data (inputs, parameters drawn from a seed, outputs) is stored.
 """
 import argparse
@@ -454,7 +456,119 @@ def gen_decode():
     save("decode_stage2", **out)
 
 
-GENS = {"decode": gen_decode, "losses": gen_losses, "daf": gen_daf, "format": gen_format, "project": gen_project, "dfa": gen_keypoints_and_dfa,
+def _stub_dataset_deps():
+    """Third-party names the reference's dataset modules import at module level (none of them is used by the functions
+    run below): permissive empty modules."""
+    import types
+
+    class Any(types.ModuleType):
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            return type(k, (), {})
+
+    for n in ["shapely", "shapely.geometry", "prettytable", "nuscenes", "nuscenes.eval", "nuscenes.eval.common",
+              "nuscenes.eval.common.utils", "nuscenes.eval.common.data_classes", "nuscenes.eval.detection",
+              "nuscenes.eval.detection.data_classes", "nuscenes.utils", "nuscenes.utils.data_classes",
+              "nuscenes.eval.detection.constants", "nuscenes.eval.detection.utils", "pyquaternion", "mmcv.fileio",
+              "mmcv.fileio.io", "mmdet.datasets", "mmdet.datasets.pipelines", "mmdet.datasets.builder"]:
+        if n not in sys.modules:
+            sys.modules[n] = Any(n)
+    sys.modules["mmcv.utils"].print_log = print
+    sys.modules["mmcv.utils"].track_iter_progress = lambda x: x
+    sys.modules["mmcv.runner"].get_dist_info = lambda: (0, 1)
+
+    class Reg:
+        def register_module(self, *a, **k):
+            return lambda c: c
+
+    sys.modules["mmdet.datasets"].DATASETS = Reg()
+    sys.modules["mmdet.datasets.builder"].PIPELINES = Reg()
+    S._ns("projects.mmdet3d_plugin.datasets.samplers", os.path.join(S.PLUGIN, "datasets", "samplers"))
+
+
+def gen_pipeline():
+    """Image leg + sampler of the reference's data pipeline, run from its own sources:
+      * ResizeCropFlipImage.__call__ / _img_transform (datasets/pipelines/augment.py:11-94; PIL does the pixels)
+      * Bench2DriveDataset.get_augmentation (datasets/bench2drive_dataset.py:709-751), numpy global RNG seeded
+      * GroupInBatchSampler (datasets/samplers/group_in_batch_sampler.py:48-178) on a toy dataset"""
+    import types
+    _stub_dataset_deps()
+    aug_mod = S.ref_import("datasets.pipelines.augment")
+    ds_mod = S.ref_import("datasets.bench2drive_dataset")
+    smp_mod = S.ref_import("datasets.samplers.group_in_batch_sampler")
+    out = {}
+    # ---- get_augmentation: 8 training draws + the test-mode value, on a small frame and on the real one ----
+    confs = {"small": {"resize_lim": (0.40, 0.47), "final_dim": (28, 64), "bot_pct_lim": (0.0, 0.0), "rot_lim": (-5.4, 5.4),
+                       "H": 90, "W": 160, "rand_flip": True, "rot3d_range": [0, 0]},
+             "b2d": {"resize_lim": (0.40, 0.47), "final_dim": (256, 704), "bot_pct_lim": (0.0, 0.0), "rot_lim": (-5.4, 5.4),
+                     "H": 900, "W": 1600, "rand_flip": True, "rot3d_range": [0, 0]}}
+    draws = {}
+    for name, conf in confs.items():
+        np.random.seed(2024)
+        me = types.SimpleNamespace(data_aug_conf=conf, test_mode=False)
+        draws[name] = [ds_mod.Bench2DriveDataset.get_augmentation(me) for _ in range(8)]
+        me.test_mode = True
+        draws[name].append(ds_mod.Bench2DriveDataset.get_augmentation(me))
+        out[f"aug_{name}"] = np.array([[d["resize"], *d["resize_dims"], *d["crop"], float(d["flip"]), d["rotate"], d["rotate_3d"]]
+                                       for d in draws[name]], np.float64)
+    # ---- the image transform on the small frames: 6 cameras, the 9 aug_configs above + two hand-made edge cases ----
+    rng = np.random.default_rng(7)
+    imgs = rng.integers(0, 256, (6, 90, 160, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:90, 0:160]
+    imgs[1] = ((yy[..., None] * np.array([2, 1, 3]) + xx[..., None] * np.array([1, 3, 2])) % 256).astype(np.uint8)   # smooth
+    imgs[2, 20:60, 30:120] = 255                                                                                    # edges
+    out["src"] = imgs
+    cases = list(draws["small"]) + [
+        {"resize": 0.5, "crop": (-3, -2, 61, 26), "flip": True, "rotate": -3.3},      # crop box leaves the image: zero fill
+        {"resize": 1.0, "crop": (10, 5, 140, 80), "flip": False, "rotate": 5.0},      # no resampling pass at all
+    ]
+    out["cases"] = np.array([[c["resize"], *c["crop"], float(c["flip"]), c["rotate"]] for c in cases], np.float64)
+    tf = aug_mod.ResizeCropFlipImage()
+    l2i = rng.normal(size=(6, 4, 4))
+    out["lidar2img"] = l2i
+    for k, c in enumerate(cases):
+        res = dict(img=[im.astype(np.float32) for im in imgs], aug_config=dict(c), lidar2img=[m.copy() for m in l2i])
+        res = tf(res)
+        out[f"img_{k}"] = np.stack(res["img"]).astype(np.uint8)        # float32 holding integers 0..255: stored as bytes
+        assert np.array_equal(out[f"img_{k}"].astype(np.float32), np.stack(res["img"]))
+        out[f"lidar2img_{k}"] = np.stack(res["lidar2img"])
+    # ---- sampler: 9 sequences of 3..11 frames, two ranks x batch 2, skipping and reversal on ----
+    lens = [5, 3, 7, 4, 11, 6, 3, 8, 5]
+    flag = np.concatenate([np.full(n, g) for g, n in enumerate(lens)])
+    flag = flag[np.random.default_rng(3).permutation(len(flag))]     # a sequence's frames are not contiguous in the dataset
+    out["sampler_flag"] = flag
+
+    class Toy:
+        keep_consistent_seq_aug = True
+
+        def __init__(self):
+            self.flag = flag
+            self.n = 0
+
+        def __len__(self):
+            return len(self.flag)
+
+        def get_augmentation(self):
+            self.n += 1
+            return self.n
+
+    for rank in (0, 1):
+        for keep in (True, False):
+            np.random.seed(100 + rank)
+            ds = Toy()
+            ds.keep_consistent_seq_aug = keep
+            sm = smp_mod.GroupInBatchSampler(ds, batch_size=2, world_size=2, rank=rank, seed=11, skip_prob=0.15,
+                                             sequence_flip_prob=0.3)
+            it = iter(sm)
+            rows = []
+            for _ in range(80):
+                rows.append([[d["idx"], d["aug_config"]] for d in next(it)])
+            out[f"sampler_rank{rank}_keep{int(keep)}"] = np.array(rows, np.int64)
+    save("image_pipeline", **out)
+
+
+GENS = {"pipeline": gen_pipeline, "decode": gen_decode, "losses": gen_losses, "daf": gen_daf, "format": gen_format, "project": gen_project, "dfa": gen_keypoints_and_dfa,
         "decoder": gen_decoder}
 
 if __name__ == "__main__":

@@ -49,8 +49,12 @@ def run(mode, steps):
 
 def test_replayed_step_tracks_eager_step():
     warnings.filterwarnings("ignore")
+    from hipad_amd import functional as HF
+    HF.LIBRARY_CALLS.clear()
     eager = run("eager", 8)[5:]      # frames 5, 6, 7
     graph = run("graph", 8)          # the same three frames, replayed
+    # no Linear / LayerNorm of the decoder took a torch / library path on the way (silent fallbacks)
+    assert not HF.LIBRARY_CALLS, dict(HF.LIBRARY_CALLS)
     assert len(eager) == len(graph) == 3
     for (le, ge), (lg, gg) in zip(eager, graph):
         assert all(map(lambda v: v == v and abs(v) < 1e6, (le, ge, lg, gg))), (eager, graph)

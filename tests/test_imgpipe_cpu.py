@@ -1,0 +1,160 @@
+"""Image leg of the data pipeline, host side: the numpy restatement (oracle/imgpipe.py)
+against Pillow itself and against the reference's own ResizeCropFlipImage output (tests/golden/image_pipeline.npz, made
+by tests/golden/make_golden.py --only pipeline from the reference's sources); the library's host-side tap tables and
+rotation constants against the restatement; get_augmentation and GroupInBatchSampler against the reference's draws."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import imgpipe as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = np.load(os.path.join(HERE, "golden", "image_pipeline.npz"))
+
+
+def case(k):
+    r = G["cases"][k]
+    return dict(resize=float(r[0]), crop=tuple(int(v) for v in r[1:5]), flip=bool(r[5]), rotate=float(r[6]))
+
+
+def test_restatement_equals_reference_output_bit_exact():
+    src = G["src"]
+    for k in range(len(G["cases"])):
+        c = case(k)
+        for cam in range(src.shape[0]):
+            got = O.img_transform(src[cam], c["resize"], c["crop"], c["flip"], c["rotate"])
+            assert got.dtype == np.float32
+            assert np.array_equal(got, G[f"img_{k}"][cam].astype(np.float32)), (k, cam)
+
+
+def test_restatement_equals_pillow_bit_exact():
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    for t in range(24):
+        H, W = int(rng.integers(40, 200)), int(rng.integers(60, 300))
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        rs = float(rng.uniform(0.3, 1.3)) if t % 5 else 1.0
+        nw, nh = int(W * rs), int(H * rs)
+        fw, fh = max(8, nw - int(rng.integers(0, 20))), max(8, nh - int(rng.integers(0, 20)))
+        cx, cy = int(rng.integers(-5, max(1, nw - fw + 5))), int(rng.integers(-5, max(1, nh - fh + 5)))
+        box, flip = (cx, cy, cx + fw, cy + fh), bool(rng.integers(0, 2))
+        ang = float(rng.uniform(-5.4, 5.4)) if t % 4 else 0.0
+        p = Image.fromarray(img).resize((nw, nh)).crop(box)
+        if flip:
+            p = p.transpose(method=Image.FLIP_LEFT_RIGHT)
+        want = np.array(p.rotate(ang)).astype(np.float32)
+        assert np.array_equal(O.img_transform(img, rs, box, flip, ang), want), t
+    # one dimension unchanged: Pillow skips only that pass
+    img = rng.integers(0, 256, (50, 80, 3), dtype=np.uint8)
+    for size in ((80, 31), (37, 50)):
+        assert np.array_equal(O.resize(img, *size), np.array(Image.fromarray(img).resize(size))), size
+
+
+def test_full_size_frame_against_pillow():
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (900, 1600, 3), dtype=np.uint8)
+    a = G["aug_b2d"][0]
+    rs, crop, flip, ang = float(a[0]), tuple(int(v) for v in a[3:7]), bool(a[7]), float(a[8])
+    p = Image.fromarray(img).resize((int(1600 * rs), int(900 * rs))).crop(crop)
+    if flip:
+        p = p.transpose(method=Image.FLIP_LEFT_RIGHT)
+    want = np.array(p.rotate(ang)).astype(np.float32)
+    assert want.shape == (256, 704, 3)
+    assert np.array_equal(O.img_transform(img, rs, crop, flip, ang), want)
+
+
+def test_library_tables_equal_restatement():
+    from hipad_amd import imgpipe as P
+    for n_in, n_out in ((1600, 704), (1600, 745), (900, 396), (900, 419), (160, 70), (90, 41), (64, 64), (50, 120), (7, 3)):
+        k, b, c = P.resample_tables(n_in, n_out)
+        ko, bo, co = O.resample_tables(n_in, n_out)
+        assert k == ko and np.array_equal(b, bo) and np.array_equal(c, co), (n_in, n_out)
+    for ang in (0.0, 360.0, -360.0, 5.4, -5.4, 1e-3, 3.3, -0.77, 12.5, 359.2, -725.5):
+        for w, h in ((704, 256), (64, 28), (130, 75)):
+            assert P.rotate_fixed(ang, w, h) == O.rotate_fixed(ang, w, h), (ang, w, h)
+    with pytest.raises(Exception):
+        P.rotate_fixed(180.0, 64, 28)          # PIL's transpose path: not the affine walk
+    with pytest.raises(Exception):
+        P.resample_tables(0, 5)
+
+
+def test_transform_matrix_equals_reference():
+    from hipad_amd import imgpipe as P
+    l2i = G["lidar2img"]
+    for k in range(len(G["cases"])):
+        c = case(k)
+        m = P.transform_matrix(c, 90, 160)
+        assert np.array_equal(m, O.transform_matrix(c["resize"], c["crop"], c["flip"], c["rotate"]))
+        want = G[f"lidar2img_{k}"]
+        got = np.stack([m @ x for x in l2i])
+        assert np.array_equal(got, want), k     # same float64 expression order as the reference
+
+
+def test_get_augmentation_reproduces_reference_draws():
+    from projects.mmdet3d_plugin.datasets import get_augmentation
+    confs = {"small": dict(final_dim=(28, 64), H=90, W=160), "b2d": dict(final_dim=(256, 704), H=900, W=1600)}
+    for name, extra in confs.items():
+        conf = dict(resize_lim=(0.40, 0.47), bot_pct_lim=(0.0, 0.0), rot_lim=(-5.4, 5.4), rand_flip=True, rot3d_range=[0, 0], **extra)
+        np.random.seed(2024)
+        draws = [get_augmentation(conf) for _ in range(8)] + [get_augmentation(conf, test_mode=True)]
+        got = np.array([[d["resize"], *d["resize_dims"], *d["crop"], float(d["flip"]), d["rotate"], d["rotate_3d"]] for d in draws])
+        assert np.array_equal(got, G[f"aug_{name}"]), name
+    assert get_augmentation(None) is None
+
+
+class ToyDataset:
+    def __init__(self, keep):
+        self.flag = G["sampler_flag"]
+        self.keep_consistent_seq_aug = keep
+        self.n = 0
+
+    def __len__(self):
+        return len(self.flag)
+
+    def get_augmentation(self):
+        self.n += 1
+        return self.n
+
+
+def test_group_in_batch_sampler_reproduces_reference_stream():
+    from projects.mmdet3d_plugin.datasets import GroupInBatchSampler
+    for rank in (0, 1):
+        for keep in (True, False):
+            np.random.seed(100 + rank)
+            sm = GroupInBatchSampler(ToyDataset(keep), batch_size=2, world_size=2, rank=rank, seed=11, skip_prob=0.15,
+                                     sequence_flip_prob=0.3)
+            it = iter(sm)
+            got = np.array([[[d["idx"], d["aug_config"]] for d in next(it)] for _ in range(80)], np.int64)
+            assert np.array_equal(got, G[f"sampler_rank{rank}_keep{int(keep)}"]), (rank, keep)
+    assert len(sm) == len(G["sampler_flag"])
+
+
+def test_slots_deal_one_permutation_stream_between_them():
+    """The sampler's point: the 4 slots of 2 ranks x batch 2 take entries slot, slot + 4, slot + 8 ... of ONE seeded
+    stream of group permutations, so one pass over the groups never hands a sequence to two slots."""
+    from projects.mmdet3d_plugin.datasets import GroupInBatchSampler
+    flag = G["sampler_flag"]
+    gen = torch.Generator()
+    gen.manual_seed(4)
+    stream = sum((torch.randperm(9, generator=gen).tolist() for _ in range(40)), [])
+    for rank in (0, 1):
+        it = iter(GroupInBatchSampler(ToyDataset(True), batch_size=2, world_size=2, rank=rank, seed=4))
+        visited, last_aug = [[], []], [None, None]
+        for _ in range(300):
+            for slot, d in enumerate(next(it)):
+                if d["aug_config"] != last_aug[slot]:          # a new sequence was taken (one augmentation per sequence)
+                    visited[slot].append(int(flag[d["idx"]]))
+                    last_aug[slot] = d["aug_config"]
+        for slot in (0, 1):
+            g = rank * 2 + slot
+            assert visited[slot] == stream[g::4][:len(visited[slot])] and len(visited[slot]) > 20
+
+
+def test_device_entry_refuses_host_tensors():
+    from hipad_amd import imgpipe as P
+    from hipad_amd.lib import HipadError
+    with pytest.raises(HipadError):
+        P.transform_images(torch.zeros(1, 8, 8, 3, dtype=torch.uint8), dict(resize=1.0))

@@ -18,16 +18,18 @@ loose = {id(p) for p, _ in step.grads._loose}
 arrivals = collections.Counter()
 for p in model.parameters():
     if p.requires_grad:
-        p.register_hook(lambda g, p=p: arrivals.__setitem__(id(p), arrivals[id(p)] + 1))
+        # the engine calls tensor hooks with None for the inputs a Function returned no gradient for: not an arrival
+        p.register_hook(lambda g, p=p: arrivals.__setitem__(id(p), arrivals[id(p)] + (g is not None)))
 step(*frames.next())
 torch.cuda.synchronize()
 cost = collections.Counter()
+shapes = {id(p): tuple(p.shape) for p in model.parameters()}
 for pid, n in arrivals.items():
     kernels = n - 1 if pid in loose else n
     if kernels > 0:
         key = ".".join(("*" if s.isdigit() else s) for s in names[pid].split("."))
         cost[(key, "loose" if pid in loose else "preset")] += kernels
-print("parameters with autograd arrivals:", len(arrivals), "loose:", len(loose), "of", len(names))
+print("parameters with autograd arrivals:", sum(1 for n in arrivals.values() if n), "loose:", len(loose), "of", len(names))
 print("accumulation kernels per step:", sum(cost.values()))
 for (k, kind), n in cost.most_common(40):
     print("%5d  %-7s %s" % (n, kind, k))
