@@ -91,10 +91,37 @@ def bf16_pair(weight):
 # chain specification
 # ------------------------------------------------------------------------------------------------------------
 class _L:
-    __slots__ = ("weight", "bias", "relu", "ln")
+    """One Linear of a chain: the whole ``weight`` [N][K] / ``bias`` [N] of a module, or -- ``rows`` = (r0, r1) -- a row
+    block of a packed projection (attention in_proj_weight), which is a contiguous [r1 - r0][K] matrix of its own."""
+    __slots__ = ("weight", "bias", "relu", "ln", "rows", "N", "K")
 
-    def __init__(self, lin):
-        self.weight, self.bias, self.relu, self.ln = lin.weight, lin.bias, False, None
+    def __init__(self, lin=None, weight=None, bias=None, rows=None):
+        self.weight, self.bias = (lin.weight, lin.bias) if lin is not None else (weight, bias)
+        self.relu, self.ln, self.rows = False, None, rows
+        self.N = self.weight.shape[0] if rows is None else rows[1] - rows[0]
+        self.K = self.weight.shape[1]
+
+    @property
+    def r0(self):
+        return 0 if self.rows is None else self.rows[0]
+
+    def operands(self):
+        """(P(W), P(W^T)) of this layer's matrix."""
+        if self.rows is None:
+            return bf16_pair(self.weight)
+        table = getattr(self.weight, "_hipad_shadow_rows", None)
+        if table is not None and self.rows in table:
+            return table[self.rows]
+        hit = getattr(self.weight, "_hipad_pair_rows", None)
+        stamp = (self.weight.data_ptr(), self.weight._version, tuple(self.weight.shape))
+        if hit is None or hit[0] != stamp:
+            hit = (stamp, {})
+            self.weight._hipad_pair_rows = hit
+        pair = hit[1].get(self.rows)
+        if pair is None:
+            w = self.weight.detach().float()[self.rows[0]:self.rows[1]]
+            pair = hit[1][self.rows] = (pack_fragments(w), pack_fragments(w.t()))
+        return pair
 
 
 class ChainSpec:
@@ -102,7 +129,7 @@ class ChainSpec:
 
     def __init__(self, layers, scale=None):
         self.layers, self.scale = layers, scale
-        self.K0, self.N_out = layers[0].weight.shape[1], layers[-1].weight.shape[0]
+        self.K0, self.N_out = layers[0].K, layers[-1].N
 
     def params(self):
         ps = []
@@ -134,7 +161,7 @@ def spec_of(seq):
                 layers[-1].relu = True
         elif isinstance(m, nn.LayerNorm):
             if (not layers or layers[-1].ln is not None or len(m.normalized_shape) != 1
-                    or m.normalized_shape[0] != layers[-1].weight.shape[0] or m.weight is None):
+                    or m.normalized_shape[0] != layers[-1].N or m.weight is None):
                 ok = False
             else:
                 layers[-1].ln = m
@@ -152,10 +179,10 @@ def spec_of(seq):
         ok = False
     if ok:
         for L in layers:
-            n, k = L.weight.shape
+            n, k = L.N, L.K
             if n > MAX_WIDTH or k > MAX_WIDTH or L.weight.dtype != torch.float32:
                 ok = False
-        if scale is not None and scale.numel() != layers[-1].weight.shape[0]:
+        if scale is not None and scale.numel() != layers[-1].N:
             ok = False
     spec = ChainSpec(layers, scale) if ok else None
     try:
@@ -288,7 +315,7 @@ class _Chains(Function):
             scale = params[-1]
             offs, total = [], 0
             for li, L in enumerate(spec.layers):
-                N = L.weight.shape[0]
+                N = L.N
                 last = li + 1 == nl
                 need_h = need_grad and ((not last) or L.relu or L.ln is not None or scale is not None)
                 oh = oy = ost = NONE
@@ -315,15 +342,15 @@ class _Chains(Function):
             shadows = []
             for li, L in enumerate(spec.layers):
                 w, b, g, bt = params[4 * li:4 * li + 4]
-                pair = bf16_pair(L.weight)
+                pair = L.operands()
                 shadows.append(pair)
                 cl = c.layers[li]
                 cl.w = pair[0].data_ptr()
-                cl.bias = b.data_ptr() if b is not None else None
+                cl.bias = b.data_ptr() + 4 * L.r0 if b is not None else None
                 cl.gamma = g.data_ptr() if g is not None else None
                 cl.beta = bt.data_ptr() if bt is not None else None
                 cl.off_h, cl.off_y, cl.off_stats = offs[li]
-                cl.N, cl.K = L.weight.shape
+                cl.N, cl.K = L.N, L.K
                 cl.flags = (1 if L.relu else 0) | (2 if L.ln is not None else 0)
                 cl.eps = float(L.ln.eps) if L.ln is not None else 0.0
             keep.append((x0v, x1v, resv, shadows, scale))
@@ -382,7 +409,7 @@ class _Chains(Function):
             keep.append(g2)
             pin = r["pin"]
             need_x = ctx.needs_input_grad[1 + pin] or (r["x1_shape"] is not None and ctx.needs_input_grad[2 + pin])
-            dy_total = sum(M * L.weight.shape[0] for L in spec.layers)
+            dy_total = sum(M * L.N for L in spec.layers)
             dy = torch.empty(dy_total, dtype=torch.float32, device=dev)
             dx = None
             c = garr[ci]
@@ -417,7 +444,7 @@ class _Chains(Function):
             c.ldo, c.M, c.nlayers = ldo, M, nl
             off = 0
             for li, L in enumerate(spec.layers):
-                N, K = L.weight.shape
+                N, K = L.N, L.K
                 cl = c.layers[li]
                 cl.wt = r["shadows"][li][1].data_ptr()
                 oh, oy, ost = r["offs"][li]
@@ -444,10 +471,10 @@ class _Chains(Function):
                         poh, poy, _ = r["offs"][li - 1]
                         d.x = r["save"].data_ptr() + 4 * (poy if spec.layers[li - 1].ln is not None else poh)
                         d.ldx = K
-                    d.dw = _acc_target(L.weight, rets, 4 * li).data_ptr()
+                    d.dw = _acc_target(L.weight, rets, 4 * li).data_ptr() + 4 * L.r0 * K
                     d.db = None
                     if L.bias is not None and ctx.needs_input_grad[1 + pin + 3 + 4 * li + 1]:
-                        d.db = _acc_target(L.bias, rets, 4 * li + 1).data_ptr()
+                        d.db = _acc_target(L.bias, rets, 4 * li + 1).data_ptr() + 4 * L.r0
                     d.M, d.N, d.K = M, N, K
                     dws.append(d)
                 off += M * N

@@ -22,8 +22,6 @@ __global__ __launch_bounds__(256) void focal_loss_kernel(float *__restrict__ los
                                                          long elems_per_layer, float alpha, float gamma, float eps) {
   __shared__ float sh[4];
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  // a block never straddles two layers when elems_per_layer % 256 == 0; otherwise fall back to per-thread atomics
-  const bool aligned = (elems_per_layer & 255) == 0;
   float val = 0.f;
   int layer = 0;
   if (i < n_elems) {
@@ -49,15 +47,28 @@ __global__ __launch_bounds__(256) void focal_loss_kernel(float *__restrict__ los
     val = l * scale;
     grad[i] = g * scale;
   }
-  if (aligned) {
+  // one atomic per block when the whole block lies in one layer, one per wavefront when only the wavefront does, one per
+  // element for the few wavefronts that straddle a layer boundary (element-wise atomics on `layers` addresses serialise:
+  // measured 170 us for 48 600 elements before this)
+  const long last = n_elems - 1;
+  const long wave_first = i - (threadIdx.x & 63);
+  const long block_first = (long)blockIdx.x * blockDim.x;
+  const int wl0 = (int)((wave_first < last ? wave_first : last) / elems_per_layer);
+  const int wl1 = (int)((wave_first + 63 < last ? wave_first + 63 : last) / elems_per_layer);
+  const int bl0 = (int)((block_first < last ? block_first : last) / elems_per_layer);
+  const int bl1 = (int)((block_first + 255 < last ? block_first + 255 : last) / elems_per_layer);
+  const bool block_uniform = bl0 == bl1;          // uniform across the block: the barrier below is safe
+  float wsum = val;
+  if (wl0 == wl1) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) val += __shfl_xor(val, o);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = val;
+    for (int o = 32; o > 0; o >>= 1) wsum += __shfl_xor(wsum, o);
+  }
+  if (block_uniform) {
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = wsum;
     __syncthreads();
-    if (threadIdx.x == 0) {
-      const long first = (long)blockIdx.x * blockDim.x;
-      if (first < n_elems) atomicAdd(loss + (int)(first / elems_per_layer), sh[0] + sh[1] + sh[2] + sh[3]);
-    }
+    if (threadIdx.x == 0 && block_first < n_elems) atomicAdd(loss + bl0, sh[0] + sh[1] + sh[2] + sh[3]);
+  } else if (wl0 == wl1) {
+    if ((threadIdx.x & 63) == 0 && wave_first < n_elems) atomicAdd(loss + wl0, wsum);
   } else if (i < n_elems) {
     atomicAdd(loss + layer, val);
   }

@@ -125,9 +125,17 @@ class TrainStep:
         # parameters, gradients and AdamW moments in flat buffers; clip + step = two launches
         # lr_config (linear warm-up + cosine annealing per iteration) is evaluated inside the optimiser kernel
         runner = cfg.get("runner") or {}
+        import importlib
+        enc = importlib.import_module("projects.mmdet3d_plugin.models.image_encoder")
+        convs = [m for m in model.modules() if isinstance(m, enc.Conv2d) and m.weight.requires_grad]
+        shadow_convs = bool(convs) and getattr(model, "encoder_dtype", None) == torch.bfloat16 and convs[0].weight.is_cuda
         self.opt = FlatAdamW([(rest, opt["lr"]), (bb, opt["lr"] * mult)], weight_decay=opt["weight_decay"],
                              max_norm=self.max_norm, comm_dtype=comm_dtype, lr_config=cfg.get("lr_config"),
-                             max_iters=int(runner.get("max_iters", 0)))
+                             max_iters=int(runner.get("max_iters", 0)), bf16_shadow=shadow_convs)
+        if shadow_convs:
+            # the encoder's convolutions read the bf16 copy of their weight that the AdamW kernel keeps current
+            for m in convs:
+                m.weight._hipad_bf16 = self.opt.shadow_of(m.weight)
         self.params = self.opt.params
         self.grads = self.opt.grads
         late = neck + bb

@@ -108,21 +108,37 @@ class FlatAdamW:
     # which hipad_amd.chain.bf16_pair prefers over its own version-keyed cache (the optimiser kernel updates
     # parameters through raw pointers, invisible to torch's version counters).
     def _attach_chain_operands(self, device):
-        mats = [p for p in self.params if p.dim() == 2 and max(p.shape) <= 256]
+        # (parameter, first row, rows): whole matrices with both dims <= 256, and the 256-row blocks of tall packed
+        # projections (attention in_proj_weight [3 E][E], E <= 256) -- a row block of a row-major matrix is itself a
+        # contiguous matrix, so it packs like one; those parameters carry ``_hipad_shadow_rows = {(r0, r1): (w, wt)}``
+        mats = []
+        for p in self.params:
+            if p.dim() != 2 or p.shape[1] > 256:
+                continue
+            n = p.shape[0]
+            if n <= 256:
+                mats.append((p, 0, n))
+            elif n % 256 == 0 and p.shape[1] == 256:
+                mats += [(p, r0, 256) for r0 in range(0, n, 256)]
         if not mats:
             return
         from .chain import packed_numel
-        total = sum(packed_numel(*p.shape) + packed_numel(p.shape[1], p.shape[0]) for p in mats)
+        total = sum(packed_numel(n, p.shape[1]) + packed_numel(p.shape[1], n) for p, _, n in mats)
         self.chain_buf = torch.zeros(total, dtype=torch.bfloat16, device=device)
         src, dst, dst_t, rows, cols, starts, tiles, off = [], [], [], [], [], [0], 0, 0
-        for p in mats:
-            n, k = p.shape
+        for p, r0, n in mats:
+            k = p.shape[1]
             w = self.chain_buf[off:off + packed_numel(n, k)]
             off += packed_numel(n, k)
             wt = self.chain_buf[off:off + packed_numel(k, n)]
             off += packed_numel(k, n)
-            p._hipad_shadow = (w, wt)
-            src.append(p.data_ptr()); dst.append(w.data_ptr()); dst_t.append(wt.data_ptr()); rows.append(n); cols.append(k)
+            if n == p.shape[0]:
+                p._hipad_shadow = (w, wt)
+            else:
+                if r0 == 0:
+                    p._hipad_shadow_rows = {}
+                p._hipad_shadow_rows[(r0, r0 + n)] = (w, wt)
+            src.append(p.data_ptr() + 4 * r0 * k); dst.append(w.data_ptr()); dst_t.append(wt.data_ptr()); rows.append(n); cols.append(k)
             tiles += ((n + 31) // 32) * ((k + 31) // 32)
             starts.append(tiles)
         i64 = lambda v: torch.tensor(v, dtype=torch.int64, device=device)  # noqa: E731

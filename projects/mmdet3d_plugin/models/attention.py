@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from hipad_amd import chain as CH
 from hipad_amd import functional as HF
 from hipad_amd.compat import ATTENTION, BaseModule, Linear, build_dropout
 
@@ -62,10 +63,35 @@ class FlashMHA(nn.Module):
         return (HF.linear(q, W, b, rows=(0, E)), HF.linear(k, W, b, rows=(E, 2 * E)),
                 HF.linear(v, W, b, rows=(2 * E, 3 * E)))
 
-    def forward(self, q, k, v, key_padding_mask=None):
+    def _project_chains(self, q, k, v, q_pos, k_pos):
+        """The three projections (positional inputs added on the fly) as ONE grouped launch of single-layer chains on
+        the 256-row blocks of the packed weight: contiguous q / k / v outputs, two backward launches."""
+        E = self.embed_dim
+        specs = getattr(self, "_hipad_proj_specs", None)
+        if specs is None:
+            specs = self._hipad_proj_specs = [
+                CH.ChainSpec([CH._L(weight=self.in_proj_weight, bias=self.in_proj_bias, rows=(i * E, (i + 1) * E))]) for i in range(3)]
+        if k is q and k_pos is q_pos and q_pos is not None:
+            q = k = q + q_pos          # shared input: one add feeds both projections (its backward is free)
+            q_pos = k_pos = None
+        return CH.run([CH.Call(specs[0], q, q_pos), CH.Call(specs[1], k, k_pos), CH.Call(specs[2], v)])
+
+    def forward(self, q, k, v, key_padding_mask=None, q_pos=None, k_pos=None):
+        """``q_pos`` / ``k_pos`` (ours, optional): positional tensors to be added to q / k before their projections."""
         if key_padding_mask is not None:
             raise NotImplementedError("key_padding_mask is not used by the decoder")
-        qp, kp, vp = self._project(q, k, v)
+        if (self.embed_dim <= CH.MAX_WIDTH and self.embed_dim % 16 == 0 and CH.usable(q) and q.dtype == torch.float32
+                and self.in_proj_weight.dtype == torch.float32):
+            qp, kp, vp = self._project_chains(q, k, v, q_pos, k_pos)
+        else:
+            if q_pos is not None:
+                shared = k is q and k_pos is q_pos
+                q = q + q_pos
+                k = q if shared else k
+                k_pos = None if shared else k_pos
+            if k_pos is not None:
+                k = k + k_pos
+            qp, kp, vp = self._project(q, k, v)
         p_drop = self.attention_dropout if self.training else 0.0
         ctx = HF.attention(qp, kp, vp, self.num_heads, scale=1.0 / math.sqrt(self.head_dim), p_drop=p_drop,
                            seed=self._seed)
@@ -107,12 +133,8 @@ class MultiheadFlashAttention(BaseModule):
                 key_pos = query_pos
             else:
                 warnings.warn(f"position encoding of key is missing in {self.__class__.__name__}.")
-        q_in = query if query_pos is None else query + query_pos
-        if self_keys and key_pos is query_pos:
-            k_in = q_in  # same tensor: lets the projection fuse q and k
-        else:
-            k_in = key if key_pos is None else key + key_pos
-        out = self.attn(q=q_in, k=k_in, v=value, key_padding_mask=key_padding_mask)[0]
+        # the positional adds are left to the projection (fused into its kernel where the chain kernels apply)
+        out = self.attn(q=query, k=key, v=value, key_padding_mask=key_padding_mask, q_pos=query_pos, k_pos=key_pos)[0]
         out = self.dropout_layer(self.proj_drop(out))
         if self.residual_mode == "concat":
             return torch.cat([identity, out], dim=2)

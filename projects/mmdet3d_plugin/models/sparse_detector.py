@@ -16,6 +16,7 @@ from hipad_amd.compat import BACKBONES, DETECTORS, HEADS, NECKS, PLUGIN_LAYERS, 
 
 from ..ops import feature_maps_format, shared_feature_grad
 from .grid_mask import GridMask
+from .image_encoder import BatchNorm2d as _EncoderBN
 
 __all__ = ["SparseDetector"]
 
@@ -46,6 +47,9 @@ class SparseDetector(BaseModule):
         for m in (self.img_backbone, self.img_neck, self.head):
             if m is not None and hasattr(m, "init_weights"):
                 m.init_weights()
+        for m in self.modules():
+            if isinstance(m, _EncoderBN):
+                m.defer_counter = True          # extract_feat flushes the queued counters once per frame
 
     def extract_feat(self, img, return_depth=False, metas=None):
         bs = img.shape[0]
@@ -61,6 +65,7 @@ class SparseDetector(BaseModule):
             levels = self.img_backbone(img)
             if self.img_neck is not None:
                 levels = self.img_neck(levels)
+            _EncoderBN.flush_counters()
         # levels stay in the encoder's dtype (bf16): the depth heads and the flat-layout copy convert on read,
         # so the pyramid is written once in fp32 (as the flat tensor) instead of twice
         levels = [f.reshape((bs, num_cams) + f.shape[1:]) for f in levels]

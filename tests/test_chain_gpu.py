@@ -287,3 +287,67 @@ def test_keep_mask_statistics_and_clock():
     assert 0.2 < float((a != c).float().mean()) < 0.3         # independent masks differ in 2 p (1 - p) = 25.5 % of the slots
     d = lib.keep_mask((1, 900, 6, 13), 0.15, 99, clock, torch.device("cuda"))
     assert 0.2 < float((c != d).float().mean()) < 0.3
+
+
+@pytest.mark.parametrize("mode", ["self", "cross"])
+def test_attention_projections_on_row_blocks_of_the_packed_weight(mode):
+    """FlashMHA's three in-projections as one grouped launch of single-layer chains on the 256-row blocks of
+    in_proj_weight, positional inputs added inside the kernel: same values and gradients (inputs, positional inputs,
+    the packed weight and bias) as fp64 torch, within the bf16 class; the module's output equals the per-layer path."""
+    from hipad_amd import functional as HF
+    from projects.mmdet3d_plugin.models.attention import MultiheadFlashAttention
+    torch.manual_seed(3)
+    E, B, Nq, Nk = 256, 1, 333, 517
+    attn = MultiheadFlashAttention(E, 8, attn_drop=0.0, dropout_layer=dict(type="Dropout", drop_prob=0.0)).cuda()
+    with torch.no_grad():
+        attn.attn.in_proj_bias.normal_(0, 0.1)
+    q = torch.randn(B, Nq, E, device="cuda", requires_grad=True)
+    qpos = torch.randn(B, Nq, E, device="cuda", requires_grad=True)
+    if mode == "self":
+        k = kpos = v = None
+    else:
+        k = torch.randn(B, Nk, E, device="cuda", requires_grad=True)
+        kpos = torch.randn(B, Nk, E, device="cuda", requires_grad=True)
+        v = torch.randn(B, Nk, E, device="cuda", requires_grad=True)
+    leaves = [t for t in (q, qpos, k, kpos, v) if t is not None] + [attn.attn.in_proj_weight, attn.attn.in_proj_bias]
+
+    def project(use_chains):
+        kk, kp, vv = (q, qpos, q) if mode == "self" else (k, kpos, v)
+        if use_chains:
+            return attn.attn._project_chains(q, kk, vv, qpos, kp)
+        qi = q + qpos
+        ki = qi if mode == "self" else kk + kp
+        return attn.attn._project(qi, ki, vv)
+
+    def ref64():
+        W, b = attn.attn.in_proj_weight.double(), attn.attn.in_proj_bias.double()
+        kk, kp, vv = (q, qpos, q) if mode == "self" else (k, kpos, v)
+        ins = ((q + qpos).double(), (kk + kp).double(), vv.double())
+        return [x @ W[i * E:(i + 1) * E].t() + b[i * E:(i + 1) * E] for i, x in enumerate(ins)]
+
+    gouts = [torch.randn(B, Nq, E, device="cuda")] + [torch.randn(B, Nq if mode == "self" else Nk, E, device="cuda") for _ in range(2)]
+
+    def grads(outs):
+        for t in leaves:
+            t.grad = None
+        torch.autograd.backward([o.float() for o in outs], gouts)
+        return [t.grad.double().clone() for t in leaves]
+
+    want = ref64()
+    gwant = grads(want)
+    for use_chains in (True, False):
+        outs = project(use_chains)
+        for o, w in zip(outs, want):
+            assert o.is_contiguous() or not use_chains
+            assert fro(o.double(), w) < 1e-2
+        for g, gw in zip(grads(outs), gwant):
+            assert fro(g, gw) < 1e-2
+    # the whole module: chains on and off agree within the bf16 class
+    outs = {}
+    for flag in (True, False):
+        HF.USE_CHAINS = flag
+        try:
+            outs[flag] = attn(query=q, key=k, value=v, query_pos=qpos, key_pos=kpos)
+        finally:
+            HF.USE_CHAINS = True
+    assert fro(outs[True], outs[False]) < 1e-2

@@ -100,3 +100,34 @@ def test_bf16_channels_last_encoder_tracks_fp32_unit_by_unit():
     print("encoder units bf16 vs fp32: worst max-rel %.4f, worst rms-rel %.4f" % (worst_max, worst_rms))
     assert worst_rms < 1.5e-2, worst_rms
     assert worst_max < 3e-2, worst_max
+
+
+@pytest.mark.gpu
+def test_shadow_weight_convolution_equals_autocast_cast():
+    """Conv2d reading the optimiser-kept bf16 copy of its weight: same output and same weight / input gradients as
+    autocast's per-call cast (bitwise: both read the round-to-nearest bf16 of the fp32 master and the gradient is the
+    bf16 one widened), with the gradient accumulated in place into the preset fp32 buffer."""
+    from hipad_amd import functional as HF
+    from projects.mmdet3d_plugin.models.image_encoder import Conv2d
+    torch.manual_seed(0)
+    for k, pad in ((1, 0), (3, 1)):
+        conv = Conv2d(64, 128, k, padding=pad, bias=False).cuda()
+        x = torch.randn(6, 64, 32, 44, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        gout = torch.randn(6, 128, 32, 44, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y0 = conv(x)
+        y0.backward(gout)
+        gw0, gx0 = conv.weight.grad.clone(), x.grad.clone()
+        conv.weight.grad = torch.zeros_like(conv.weight)
+        x.grad = None
+        conv.weight._hipad_bf16 = conv.weight.detach().to(torch.bfloat16)
+        HF.INPLACE_PARAMS.discard(id(conv.weight))
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y1 = conv(x)
+        held = conv.weight.grad
+        y1.backward(gout)
+        assert conv.weight.grad is held and id(conv.weight) in HF.INPLACE_PARAMS      # accumulated in place
+        assert torch.equal(y0, y1) and torch.equal(gx0, x.grad) and torch.equal(gw0, conv.weight.grad)
+        # outside autocast (fp32 run) the module is a plain nn.Conv2d
+        y2 = conv(x.detach())
+        assert y2.dtype == torch.float32
