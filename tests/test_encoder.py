@@ -105,8 +105,8 @@ def test_bf16_channels_last_encoder_tracks_fp32_unit_by_unit():
 @pytest.mark.gpu
 def test_shadow_weight_convolution_equals_autocast_cast():
     """Conv2d reading the optimiser-kept bf16 copy of its weight: same output and same weight / input gradients as
-    autocast's per-call cast (bitwise: both read the round-to-nearest bf16 of the fp32 master and the gradient is the
-    bf16 one widened), with the gradient accumulated in place into the preset fp32 buffer."""
+    autocast's per-call cast (both read the round-to-nearest bf16 of the fp32 master and the gradient is the bf16 one
+    widened), with the gradient accumulated in place into the preset fp32 buffer."""
     from hipad_amd import functional as HF
     from projects.mmdet3d_plugin.models.image_encoder import Conv2d
     torch.manual_seed(0)
@@ -127,7 +127,10 @@ def test_shadow_weight_convolution_equals_autocast_cast():
         held = conv.weight.grad
         y1.backward(gout)
         assert conv.weight.grad is held and id(conv.weight) in HF.INPLACE_PARAMS      # accumulated in place
-        assert torch.equal(y0, y1) and torch.equal(gx0, x.grad) and torch.equal(gw0, conv.weight.grad)
+        # same operands, but MIOpen may pick another solver on the second call of a shape (different summation order):
+        # bf16-rounding-level agreement, not bitwise
+        for a, b in ((y0, y1), (gx0, x.grad), (gw0, conv.weight.grad)):
+            assert float((a.float() - b.float()).norm() / b.float().norm()) < 5e-3
         # outside autocast (fp32 run) the module is a plain nn.Conv2d
         y2 = conv(x.detach())
         assert y2.dtype == torch.float32
