@@ -102,6 +102,34 @@ __global__ __launch_bounds__(256) void keep_mask_kernel(float *__restrict__ out,
   out[i] = x >= thresh ? inv_keep : 0.f;
 }
 
+// out[i] = base[i] + keep(i) * x[i] / (1 - p)  (base may be NULL): the identity connection of the attention and FFN
+// blocks, `identity + dropout(x)` (reference models/attention.py:283-289 dropout_layer + residual,
+// models/blocks.py:383-396), as one launch; the same kernel with base = NULL applied to the output gradient is its
+// backward -- the mask is recomputed from (seed, device step counter, i) like keep_mask_kernel's, never stored.
+__global__ __launch_bounds__(256) void dropout_add_kernel(float *__restrict__ out, const float *__restrict__ x,
+                                                          const float *__restrict__ base, long n4, uint32_t thresh,
+                                                          float inv_keep, uint32_t seed, const uint32_t *__restrict__ seed_dev) {
+  const long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i4 >= n4) return;
+  const uint32_t s0 = seed + (seed_dev ? *seed_dev * 0x9E3779B9u : 0u);
+  const float4 v = reinterpret_cast<const float4 *>(x)[i4];
+  float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (base) b = reinterpret_cast<const float4 *>(base)[i4];
+  const float in[4] = {v.x, v.y, v.z, v.w};
+  float o[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long i = i4 * 4 + k;
+    uint32_t h = s0 ^ ((uint32_t)i * 0xC2B2AE3Du);
+    h = (h ^ (h >> 15)) * 0x2C1B3C6Du;
+    h ^= (uint32_t)(i >> 32) * 0x27D4EB2Fu + 0x165667B1u;
+    h = (h ^ (h >> 13)) * 0x297A2D39u;
+    h ^= h >> 16;
+    if (h >= thresh) o[k] += in[k] * inv_keep;
+  }
+  reinterpret_cast<float4 *>(out)[i4] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 }  // namespace hipad
 
 using namespace hipad;
@@ -129,6 +157,18 @@ int hipad_keep_mask(float *out, long long n, float p_drop, unsigned seed, const 
   const uint32_t thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
   hipLaunchKernelGGL(keep_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, (long)n,
                      thresh, 1.f / (1.f - p_drop), seed, seed_dev);
+  return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
+}
+
+int hipad_dropout_add(float *out, const float *x, const float *base, long long n, float p_drop, unsigned seed,
+                      const unsigned *seed_dev, hipad_stream_t stream) {
+  if (!out || !x || n <= 0 || (n & 3) || !(p_drop >= 0.f) || !(p_drop < 1.f)) return HIPAD_EINVAL;
+  if ((((uintptr_t)out | (uintptr_t)x | (uintptr_t)base) & 15) != 0) return HIPAD_EINVAL;
+  const double t = (double)p_drop * 4294967296.0;
+  const uint32_t thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+  const long n4 = (long)(n / 4);
+  hipLaunchKernelGGL(dropout_add_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, x, base,
+                     n4, thresh, 1.f / (1.f - p_drop), seed, seed_dev);
   return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
 }
 

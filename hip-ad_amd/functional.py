@@ -120,6 +120,32 @@ def attention(q, k, v, heads, scale=None, p_drop=0.0, seed=0):
     return _Attention.apply(q, k, v, heads, float(scale), float(p_drop), int(seed))
 
 
+class _DropoutAdd(Function):
+    @staticmethod
+    def forward(ctx, x, identity, p_drop, seed):
+        ctx.cfg = (p_drop, seed, dropout_clock(x.device))
+        return _lib.dropout_add(_c32(x), _c32(identity), p_drop, seed, ctx.cfg[2])
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        p_drop, seed, clock = ctx.cfg
+        dout = _c32(dout)
+        dx = _lib.dropout_add(dout, None, p_drop, seed, clock) if ctx.needs_input_grad[0] else None
+        return dx, (dout if ctx.needs_input_grad[1] else None), None, None
+
+
+def dropout_add(x, identity, p_drop, seed, training=True):
+    """identity + dropout(x) as one launch (backward: one launch for dx, the identity branch passes the gradient on);
+    the mask is a function of (seed, dropout clock, element index) -- pass a per-module constant as ``seed``."""
+    if not training or p_drop <= 0.0:
+        return identity + x
+    if not (x.is_cuda and x.dtype == torch.float32 and identity.dtype == torch.float32 and x.shape == identity.shape
+            and x.numel() % 4 == 0):
+        return identity + torch.nn.functional.dropout(x, p_drop, True)
+    return _DropoutAdd.apply(x, identity, float(p_drop), int(seed))
+
+
 import os as _os
 
 LINEAR_MODE = _os.environ.get("HIPAD_LINEAR_MODE", "mfma_bf16")  # "torch_fp32": library fp32 GEMMs (fp32 parity runs)

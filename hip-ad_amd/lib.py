@@ -46,6 +46,7 @@ SIGNATURES = {
     "hipad_lr_factor": (ctypes.c_float, [c_void_p, c_int]),
     "hipad_keep_mask": (c_int, [c_void_p, ctypes.c_longlong, ctypes.c_float, ctypes.c_uint, c_void_p, c_void_p]),
     "hipad_chunk_mix": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "hipad_dropout_add": (c_int, [c_void_p] * 3 + [ctypes.c_longlong, ctypes.c_float, ctypes.c_uint, c_void_p, c_void_p]),
     "hipad_resample_tables": (c_int, [c_int, c_int, c_void_p, c_void_p]),
     "hipad_rotate_fixed": (c_int, [ctypes.c_double, c_int, c_int, c_void_p]),
     "hipad_image_resize_rows": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
@@ -532,6 +533,21 @@ def focal_loss_forward(logits, target, weight, avg_factor, layers, alpha, gamma)
                                           stream_ptr(logits.device))
     check(st, "hipad_focal_loss_forward")
     return loss, grad
+
+
+def dropout_add(x, base, p_drop, seed, seed_dev):
+    """base + dropout(x) (base None: dropout(x) alone, i.e. the backward on an output gradient); fp32 contiguous."""
+    lib = load()
+    _req(x, torch.float32, "x")
+    if base is not None:
+        _req(base, torch.float32, "base")
+        if base.shape != x.shape:
+            raise HipadError("dropout_add: shapes differ")
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(lib.hipad_dropout_add(out.data_ptr(), x.data_ptr(), _ptr(base), x.numel(), float(p_drop), int(seed) & 0xFFFFFFFF,
+                                    _ptr(seed_dev), stream_ptr(x.device)), "hipad_dropout_add")
+    return out
 
 
 def chunk_mix(x0, x1, table, rows):

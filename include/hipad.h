@@ -426,8 +426,14 @@ int hipad_pack_weights(unsigned short *const *dst, unsigned short *const *dst_t,
  *   models/blocks.py:209-212; rand, compare, cast, rescale = four launches): out[i] = 1 / (1 - p_drop) with probability
  *   1 - p_drop else 0, drawn from (seed, *seed_dev, i) -- seed_dev (may be NULL) is a device step counter, so a replayed
  *   hipGraph draws a fresh mask every step.
+ * hipad_dropout_add.  Replaces: `identity + dropout(x)` at the end of the attention and FFN blocks (reference
+ *   models/attention.py:283-289, models/blocks.py:383-396; dropout + add = two launches forward): out[i] = base[i] +
+ *   (keep(i) ? x[i] / (1 - p_drop) : 0), base may be NULL (then the call is the backward: x = output gradient).  The mask
+ *   is a function of (seed, *seed_dev, i) as in hipad_keep_mask and is never stored.  n % 4 == 0, 16-byte aligned.
  * ---------------------------------------------------------------------------------- */
 #define HIPAD_MIX_MAX 16
+int hipad_dropout_add(float *out, const float *x, const float *base, long long n, float p_drop, unsigned seed,
+                      const unsigned *seed_dev, hipad_stream_t stream);
 int hipad_keep_mask(float *out, long long n, float p_drop, unsigned seed, const unsigned *seed_dev, hipad_stream_t stream);
 int hipad_chunk_mix(float *out, const float *x0, const float *x1, const float *weights, int bs, int in_chunks,
                     int out_chunks, int rows, int channels, hipad_stream_t stream);

@@ -135,6 +135,11 @@ class MultiheadFlashAttention(BaseModule):
                 warnings.warn(f"position encoding of key is missing in {self.__class__.__name__}.")
         # the positional adds are left to the projection (fused into its kernel where the chain kernels apply)
         out = self.attn(q=query, k=key, v=value, key_padding_mask=key_padding_mask, q_pos=query_pos, k_pos=key_pos)[0]
+        if (self.residual_mode != "concat" and isinstance(self.dropout_layer, nn.Dropout) and self.proj_drop.p == 0.0
+                and out.is_cuda):
+            if not hasattr(self, "_drop_seed"):
+                self._drop_seed = HF.new_call_site_seed()
+            return HF.dropout_add(out, identity, self.dropout_layer.p, self._drop_seed, self.training)       # one launch
         out = self.dropout_layer(self.proj_drop(out))
         if self.residual_mode == "concat":
             return torch.cat([identity, out], dim=2)

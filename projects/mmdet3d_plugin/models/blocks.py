@@ -236,10 +236,15 @@ class AsymmetricFFN(BaseModule):
     def forward(self, x, identity=None):
         if self.pre_norm is not None:
             x = self.pre_norm(x)
-        out = self.dropout_layer(self.layers(x))
+        out = self.layers(x)
         if not self.add_identity:
-            return out
-        return self.identity_fc(x if identity is None else identity) + out
+            return self.dropout_layer(out)
+        base = self.identity_fc(x if identity is None else identity)
+        if isinstance(self.dropout_layer, nn.Dropout) and out.is_cuda:
+            if not hasattr(self, "_drop_seed"):
+                self._drop_seed = HF.new_call_site_seed()
+            return HF.dropout_add(out, base, self.dropout_layer.p, self._drop_seed, self.training)   # one launch
+        return base + self.dropout_layer(out)
 
 
 @PLUGIN_LAYERS.register_module()

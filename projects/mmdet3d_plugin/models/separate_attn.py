@@ -48,6 +48,50 @@ def _gather(pieces, idx):
     return pieces[idx[0]] if len(idx) == 1 else torch.cat([pieces[i] for i in idx], dim=1)
 
 
+def _run(idx):
+    """(first, last + 1) when the modality indices of a group are consecutive, else None."""
+    idx = list(idx)
+    return (idx[0], idx[-1] + 1) if idx == list(range(idx[0], idx[-1] + 1)) else None
+
+
+def _partition(runs, n):
+    """The runs, sorted, plus the gaps between them as runs of their own -- or None when two runs overlap."""
+    out, at = [], 0
+    for i0, i1 in sorted(runs):
+        if i0 < at:
+            return None
+        if i0 > at:
+            out.append((at, i0))
+        out.append((i0, i1))
+        at = i1
+    if at < n:
+        out.append((at, n))
+    return out
+
+
+def _split_runs(tensor, cumsum, part):
+    """{run: view} of a (bs, tokens, C) tensor split ONCE at the run boundaries."""
+    if tensor is None:
+        return None
+    sizes = [int(cumsum[i1]) - int(cumsum[i0]) for i0, i1 in part]
+    return dict(zip(part, torch.split(tensor, sizes, dim=1)))
+
+
+def _views(tensor, cumsum, runs, n):
+    """{run: view} for the (possibly overlapping) runs the key groups name: one split when they tile, else one split
+    at modality granularity plus a plain slice for every run that spans several modalities."""
+    if tensor is None:
+        return None
+    part = _partition(set(runs), n)
+    if part is not None:
+        return _split_runs(tensor, cumsum, part)
+    out = _split_runs(tensor, cumsum, [(i, i + 1) for i in range(n)])
+    for i0, i1 in set(runs):
+        if (i0, i1) not in out:
+            out[(i0, i1)] = tensor[:, int(cumsum[i0]):int(cumsum[i1])]
+    return out
+
+
 class _GroupedAttention(nn.Module):
     def _setup(self, attn, query_select, query_groups, key_groups, decouple_list):
         if query_groups is None or decouple_list is None:
@@ -64,8 +108,61 @@ class _GroupedAttention(nn.Module):
 
     def _route(self, query, key, value, query_pos, key_pos, q_cumsum, k_cumsum, fc_before, fc_after,
                read_updated=False, attn_mask=None):
+        """Groups whose modalities are neighbours in the token order (all groups of the HiP-AD configs: [plan, ego],
+        [det, map]) read ONE piece of a split made at group granularity -- no gather copies of queries, positional
+        embeddings, keys and values, and a backward of one concatenation per split tensor."""
         if attn_mask is not None:
             raise NotImplementedError("attention masks are not used by the HiP-AD configs")
+        n = len(self.query_select)
+        self_attend = key is None
+        q_runs = [_run(self._indices(g)) for g in self._qgroups]
+        k_runs = None if self_attend else [_run(self._indices(g)) for g in self._kgroups]
+        same_parent = (not self_attend) and key is query
+        wanted = set(q_runs) | (set(k_runs) if same_parent else set())
+        part_q = None if None in wanted else _partition(wanted, n)
+        if part_q is None or (k_runs is not None and None in k_runs):
+            return self._route_pieces(query, key, value, query_pos, key_pos, q_cumsum, k_cumsum, fc_before, fc_after,
+                                      read_updated)
+        qd, qposd = _split_runs(query, q_cumsum, part_q), _split_runs(query_pos, q_cumsum, part_q)
+        same_kv = (not self_attend) and value is key
+        if self_attend:
+            kd = kposd = None
+            vd = None if value is None else (qd if value is query else _split_runs(value, q_cumsum, part_q))
+        else:
+            if same_parent:
+                kd, kposd = qd, (qposd if key_pos is query_pos else _views(key_pos, k_cumsum, k_runs, n))
+            else:
+                kd, kposd = _views(key, k_cumsum, k_runs, n), _views(key_pos, k_cumsum, k_runs, n)
+            vd = None if value is None else (kd if same_kv else _views(value, k_cumsum, k_runs, n))
+        out_d = dict(qd)        # runs that no group writes keep the input tokens
+        for g, attn in enumerate(self.attns):
+            run = q_runs[g]
+            q, qpos = (out_d if read_updated else qd)[run], (None if qposd is None else qposd[run])
+            if self_attend:
+                k = kpos = None
+                v_in = None if vd is None else vd[run]
+            else:
+                kr = k_runs[g]
+                k, kpos = kd[kr], (None if kposd is None else kposd[kr])
+                v_in = None if vd is None else vd[kr]
+                if k.shape[1] == 0:  # nothing cached for these modalities: attend within the queries
+                    k = kpos = None
+                if v_in is not None and v_in.shape[1] == 0:
+                    v_in = None
+            if self.decouple_list[g]:
+                q = torch.cat([q, qpos], dim=-1)
+                if k is not None:
+                    k = torch.cat([k, kpos], dim=-1)
+                if v_in is not None:
+                    v_in = fc_before(v_in)
+                out_d[run] = fc_after(attn(query=q, key=k, value=v_in, query_pos=None, key_pos=None))
+            else:
+                out_d[run] = attn(query=q, key=k, value=v_in, query_pos=qpos, key_pos=kpos)
+        return torch.cat([out_d[r] for r in part_q], dim=1)
+
+    def _route_pieces(self, query, key, value, query_pos, key_pos, q_cumsum, k_cumsum, fc_before, fc_after,
+                      read_updated=False):
+        """General form (a group may name any subset of modalities): per-modality pieces, gathered per group."""
         self_attend = key is None
         q_parts, qpos_parts = _pieces(query, q_cumsum), _pieces(query_pos, q_cumsum)
         same_kv = (not self_attend) and value is key

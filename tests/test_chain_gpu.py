@@ -351,3 +351,32 @@ def test_attention_projections_on_row_blocks_of_the_packed_weight(mode):
         finally:
             HF.USE_CHAINS = True
     assert fro(outs[True], outs[False]) < 1e-2
+
+
+def test_dropout_add_is_inverted_dropout_with_a_replayable_mask():
+    """identity + dropout(x) in one launch: every element is either identity or identity + x / (1 - p), the keep rate is
+    1 - p, the backward applies the SAME mask to the output gradient, the mask changes with the dropout clock and with
+    the call-site seed, and p = 0 / eval are the plain sum."""
+    from hipad_amd import functional as HF
+    torch.manual_seed(0)
+    x = torch.randn(2, 700, 256, device="cuda", requires_grad=True)
+    idt = torch.randn(2, 700, 256, device="cuda", requires_grad=True)
+    p = 0.1
+    y = HF.dropout_add(x, idt, p, 12345)
+    kept = (y - idt).detach().abs() > 0
+    assert torch.allclose((y - idt)[kept], (x / (1 - p))[kept], rtol=1e-6, atol=1e-6)
+    rate = float(kept.float().mean())
+    assert abs(rate - (1 - p)) < 5e-3, rate
+    g = torch.randn_like(y)
+    y.backward(g)
+    assert torch.equal(idt.grad, g)
+    assert torch.allclose(x.grad, torch.where(kept, g / (1 - p), torch.zeros_like(g)), rtol=1e-6, atol=0)
+    y2 = HF.dropout_add(x, idt, p, 12345)
+    assert torch.equal(y2, y)                                   # same clock, same seed: same mask (graph replay of a backward)
+    HF.advance_dropout_clock(x.device)
+    y3 = HF.dropout_add(x, idt, p, 12345)
+    y4 = HF.dropout_add(x, idt, p, 54321)
+    for other in (y3, y4):
+        changed = float((((other - idt).abs() > 0) != kept).float().mean())
+        assert 0.1 < changed < 0.26, changed                    # independent masks differ on 2 p (1 - p) = 18 % of elements
+    assert torch.equal(HF.dropout_add(x, idt, 0.0, 1), idt + x) and torch.equal(HF.dropout_add(x, idt, p, 1, training=False), idt + x)
