@@ -130,6 +130,48 @@ __global__ __launch_bounds__(256) void dropout_add_kernel(float *__restrict__ ou
   reinterpret_cast<float4 *>(out)[i4] = make_float4(o[0], o[1], o[2], o[3]);
 }
 
+// GridMask on the device in one launch (reference models/grid_mask.py:92-138 for the detector's settings: rotate = 1,
+// offset = False): out = x * mask, mask = product of the row and the column stripe patterns of this step's draw
+// params = [apply, d, l, st_h, st_w] (device memory, written outside a hipGraph), optionally inverted (mode 1), identity
+// when apply == 0.  Reads NCHW fp32, writes fp32 or bf16 with the caller's element strides (channels-last bf16 = what
+// the encoder's first convolution consumes: no separate cast and re-layout passes).
+__device__ __forceinline__ bool gm_inside(int idx, int length, int canvas, float d, float ln, float st) {
+  const float pos = (float)(idx + (canvas - length) / 2);
+  const float k = floorf((pos - st) / d);
+  return pos >= st && k < floorf((float)canvas / d) && (pos - st) - k * d < ln;
+}
+
+__global__ __launch_bounds__(256) void grid_mask_kernel(void *__restrict__ out, const float *__restrict__ x,
+                                                        const float *__restrict__ params, int n, int c, int h, int w,
+                                                        int use_h, int use_w, int mode, int out_bf16, long sn, long sc,
+                                                        long sy, long sx) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)n * h * w;
+  if (idx >= total) return;
+  const int px = (int)(idx % w);
+  const long t = idx / w;
+  const int py = (int)(t % h), img = (int)(t / h);
+  const float apply = params[0], d = params[1], ln = params[2], st_h = params[3], st_w = params[4];
+  float m = 1.f;
+  if (apply > 0.f) {
+    const float rows = (use_h && gm_inside(py, h, (int)(1.5 * h), d, ln, st_h)) ? 0.f : 1.f;
+    const float cols = (use_w && gm_inside(px, w, (int)(1.5 * w), d, ln, st_w)) ? 0.f : 1.f;
+    m = rows * cols;
+    if (mode == 1) m = 1.f - m;
+  }
+  for (int ch = 0; ch < c; ++ch) {
+    const float v = x[(((long)img * c + ch) * h + py) * w + px] * m;
+    const long o = (long)img * sn + (long)ch * sc + (long)py * sy + (long)px * sx;
+    if (out_bf16) {
+      uint32_t u = __float_as_uint(v);
+      u += 0x7FFFu + ((u >> 16) & 1u);                 // round to nearest even (finite inputs: pixel values)
+      reinterpret_cast<uint16_t *>(out)[o] = (uint16_t)(u >> 16);
+    } else {
+      reinterpret_cast<float *>(out)[o] = v;
+    }
+  }
+}
+
 }  // namespace hipad
 
 using namespace hipad;
@@ -169,6 +211,16 @@ int hipad_dropout_add(float *out, const float *x, const float *base, long long n
   const long n4 = (long)(n / 4);
   hipLaunchKernelGGL(dropout_add_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, x, base,
                      n4, thresh, 1.f / (1.f - p_drop), seed, seed_dev);
+  return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
+}
+
+int hipad_grid_mask(void *out, int out_bf16, const long long *out_strides, const float *x, const float *params, int n, int c,
+                    int h, int w, int use_h, int use_w, int mode, hipad_stream_t stream) {
+  if (!out || !out_strides || !x || !params || n <= 0 || c <= 0 || h <= 1 || w <= 1) return HIPAD_EINVAL;
+  const long total = (long)n * h * w;
+  hipLaunchKernelGGL(grid_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, x, params,
+                     n, c, h, w, use_h ? 1 : 0, use_w ? 1 : 0, mode, out_bf16 ? 1 : 0, (long)out_strides[0],
+                     (long)out_strides[1], (long)out_strides[2], (long)out_strides[3]);
   return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
 }
 

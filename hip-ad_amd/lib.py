@@ -46,6 +46,7 @@ SIGNATURES = {
     "hipad_lr_factor": (ctypes.c_float, [c_void_p, c_int]),
     "hipad_keep_mask": (c_int, [c_void_p, ctypes.c_longlong, ctypes.c_float, ctypes.c_uint, c_void_p, c_void_p]),
     "hipad_chunk_mix": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "hipad_grid_mask": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "hipad_dropout_add": (c_int, [c_void_p] * 3 + [ctypes.c_longlong, ctypes.c_float, ctypes.c_uint, c_void_p, c_void_p]),
     "hipad_resample_tables": (c_int, [c_int, c_int, c_void_p, c_void_p]),
     "hipad_rotate_fixed": (c_int, [ctypes.c_double, c_int, c_int, c_void_p]),
@@ -533,6 +534,23 @@ def focal_loss_forward(logits, target, weight, avg_factor, layers, alpha, gamma)
                                           stream_ptr(logits.device))
     check(st, "hipad_focal_loss_forward")
     return loss, grad
+
+
+def grid_mask(x, params, use_h, use_w, mode, out_dtype=torch.float32, channels_last=False):
+    """x (n, c, h, w) fp32 * stripe mask of ``params`` = [apply, d, l, st_h, st_w] (device) -> ``out_dtype`` tensor."""
+    lib = load()
+    _req(x, torch.float32, "x"); _req(params, torch.float32, "params")
+    if out_dtype not in (torch.float32, torch.bfloat16):
+        raise HipadError("grid_mask: out_dtype must be float32 or bfloat16")
+    n, c, h, w = x.shape
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device,
+                      memory_format=torch.channels_last if channels_last else torch.contiguous_format)
+    strides = (ctypes.c_longlong * 4)(*out.stride())
+    with torch.cuda.device(x.device):
+        check(lib.hipad_grid_mask(out.data_ptr(), int(out_dtype == torch.bfloat16), strides, x.data_ptr(), params.data_ptr(),
+                                  n, c, h, w, int(bool(use_h)), int(bool(use_w)), int(mode), stream_ptr(x.device)),
+              "hipad_grid_mask")
+    return out
 
 
 def dropout_add(x, base, p_drop, seed, seed_dev):

@@ -430,8 +430,14 @@ int hipad_pack_weights(unsigned short *const *dst, unsigned short *const *dst_t,
  *   models/attention.py:283-289, models/blocks.py:383-396; dropout + add = two launches forward): out[i] = base[i] +
  *   (keep(i) ? x[i] / (1 - p_drop) : 0), base may be NULL (then the call is the backward: x = output gradient).  The mask
  *   is a function of (seed, *seed_dev, i) as in hipad_keep_mask and is never stored.  n % 4 == 0, 16-byte aligned.
+ * hipad_grid_mask.  Replaces: GridMask.forward (reference models/grid_mask.py:92-138; the detector's settings rotate = 1,
+ *   offset = False): out = x * mask with the stripe mask evaluated per pixel from params = [apply, d, l, st_h, st_w] in
+ *   device memory (this step's draw, uploaded outside a hipGraph).  x: (n, c, h, w) fp32 contiguous; out: fp32 or bf16
+ *   (out_bf16) at out[n s0 + c s1 + y s2 + x s3] (element strides), e.g. bf16 channels-last for the first convolution.
  * ---------------------------------------------------------------------------------- */
 #define HIPAD_MIX_MAX 16
+int hipad_grid_mask(void *out, int out_bf16, const long long *out_strides, const float *x, const float *params, int n, int c,
+                    int h, int w, int use_h, int use_w, int mode, hipad_stream_t stream);
 int hipad_dropout_add(float *out, const float *x, const float *base, long long n, float p_drop, unsigned seed,
                       const unsigned *seed_dev, hipad_stream_t stream);
 int hipad_keep_mask(float *out, long long n, float p_drop, unsigned seed, const unsigned *seed_dev, hipad_stream_t stream);

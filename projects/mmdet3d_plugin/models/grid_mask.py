@@ -72,6 +72,13 @@ class GridMask(nn.Module):
         if not getattr(self, "external_randomize", False):
             self.randomize(x.device)
         p = self._dev
+        if (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and not self.offset and not x.requires_grad
+                and self.mode in (0, 1)):
+            # one launch; ``out_dtype`` / ``out_channels_last`` (set by the detector) make it hand the encoder's first
+            # convolution its bf16 channels-last input directly
+            from hipad_amd import lib as _lib
+            return _lib.grid_mask(x, p, self.use_h, self.use_w, self.mode, getattr(self, "out_dtype", torch.float32),
+                                  getattr(self, "out_channels_last", False))
         apply, d, ln, st_h, st_w = p[0], p[1], p[2], p[3], p[4]
         hh, ww = int(1.5 * h), int(1.5 * w)
         rows = self._stripes(h, hh, d, ln, st_h, x.device) if self.use_h else torch.ones(h, device=x.device)

@@ -59,6 +59,9 @@ class SparseDetector(BaseModule):
         else:
             num_cams = 1
         if self.use_grid_mask:
+            # in training the mask kernel writes the encoder's input format (dtype + channels-last) in the same pass
+            self.grid_mask.out_dtype = self.encoder_dtype if img.is_cuda else torch.float32
+            self.grid_mask.out_channels_last = True
             img = self.grid_mask(img)
         img = img.contiguous(memory_format=torch.channels_last)
         with torch.autocast("cuda", dtype=self.encoder_dtype, enabled=img.is_cuda and self.encoder_dtype != torch.float32):

@@ -134,3 +134,29 @@ def test_shadow_weight_convolution_equals_autocast_cast():
         # outside autocast (fp32 run) the module is a plain nn.Conv2d
         y2 = conv(x.detach())
         assert y2.dtype == torch.float32
+
+
+@pytest.mark.gpu
+def test_grid_mask_kernel_equals_the_torch_construction():
+    """GridMask in one launch (hipad_grid_mask) against the module's own torch construction of the same mask (run on CPU
+    tensors with the same drawn parameters): equal bit for bit in fp32; the bf16 channels-last output the encoder
+    consumes equals the fp32 result rounded to bf16."""
+    from projects.mmdet3d_plugin.models.grid_mask import GridMask
+    torch.manual_seed(0)
+    x = torch.randn(6, 3, 64, 176) * 50
+    for mode in (0, 1):
+        gm = GridMask(True, True, rotate=1, offset=False, ratio=0.5, mode=mode, prob=0.7).train()
+        gm.external_randomize = True
+        for params in ([1, 40, 20, 7, 33], [1, 2, 1, 0, 1], [1, 63, 31, 62, 5], [0, 40, 20, 7, 33], [1, 17, 9, 16, 16]):
+            p = torch.tensor(params, dtype=torch.float32)
+            gm._dev = p
+            want = gm(x)
+            gm._dev = p.cuda()
+            gm.out_dtype, gm.out_channels_last = torch.float32, False
+            got = gm(x.cuda())
+            assert torch.equal(got.cpu(), want), (mode, params)
+            gm.out_dtype, gm.out_channels_last = torch.bfloat16, True
+            got16 = gm(x.cuda())
+            assert got16.dtype == torch.bfloat16 and got16.is_contiguous(memory_format=torch.channels_last)
+            assert torch.equal(got16.cpu(), want.to(torch.bfloat16)), (mode, params)
+    assert gm.eval()(x) is x
