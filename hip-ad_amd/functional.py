@@ -120,6 +120,91 @@ def attention(q, k, v, heads, scale=None, p_drop=0.0, seed=0):
     return _Attention.apply(q, k, v, heads, float(scale), float(p_drop), int(seed))
 
 
+class _ZeroArena:
+    """Zero-initialised fp32 scratch handed out in slices and cleared by ONE fill per frame: the partial-sum buffers of
+    the BatchNorm kernels must be zero on entry, and a torch.zeros per layer would cost the launch the fusion saves.
+    ``reset()`` (SparseDetector.extract_feat, before the encoder runs) clears everything handed out since the last reset;
+    a slice stays untouched until the call that consumes it -- the backward's slice is reserved during the forward."""
+
+    def __init__(self):
+        self.buf, self.used, self.high = None, 0, 0
+
+    def reset(self, device, capacity=1 << 20):
+        if self.buf is None or self.buf.device != torch.device(device) or self.buf.numel() < max(capacity, self.high):
+            self.buf = torch.zeros(max(capacity, 2 * self.high), dtype=torch.float32, device=device)
+        else:
+            self.buf[:max(self.used, 1)].zero_()
+        self.used = 0
+
+    def take(self, n, device):
+        n = (n + 63) // 64 * 64
+        if self.buf is None or self.buf.device != torch.device(device) or self.used + n > self.buf.numel():
+            self.high = max(self.high, self.used + n)
+            return torch.zeros(n, dtype=torch.float32, device=device)     # outside a reset() cycle / arena too small
+        out = self.buf[self.used:self.used + n]
+        self.used += n
+        self.high = max(self.high, self.used)
+        return out
+
+
+BN_ARENA = _ZeroArena()
+
+
+class _BatchNormAct(Function):
+    """relu?(batch_norm(x) (+ residual)) on the two fused kernels (csrc/batchnorm.hip); x bf16 channels-last."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, eps, momentum, relu):
+        c = x.shape[1]
+        n = _lib.BN_REPLICAS * 2 * c
+        sums = BN_ARENA.take(n, x.device)
+        ctx.gsums = BN_ARENA.take(n, x.device) if any(ctx.needs_input_grad[:4]) else None
+        y, save = _lib.bn_forward(x, residual, weight.detach(), bias.detach(), running_mean, running_var, sums, eps, momentum, relu)
+        ctx.save_for_backward(x, y if relu else None, save)
+        ctx.weight, ctx.bias, ctx.has_res = weight, bias, residual is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, y, save = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
+        if dy.dtype != x.dtype or not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        rets = [None, None]
+        targets = []
+        for i, p in enumerate((weight, bias)):
+            g = p.grad if (LINEAR_INPLACE_GRAD and p.is_leaf and ctx.needs_input_grad[1 + i]) else None
+            if g is not None and g.is_contiguous() and g.dtype == torch.float32:
+                INPLACE_PARAMS.add(id(p))
+                targets.append(g)
+            elif ctx.needs_input_grad[1 + i]:
+                rets[i] = torch.zeros_like(p, dtype=torch.float32)
+                targets.append(rets[i])
+            else:
+                targets.append(None)
+        gsums, ctx.gsums = ctx.gsums, None          # the reserved slice is zero only once (retain_graph: fresh zeros after)
+        if gsums is None:
+            gsums = torch.zeros(_lib.BN_REPLICAS * 2 * x.shape[1], dtype=torch.float32, device=x.device)
+        dx, dres = _lib.bn_backward(dy, y, x, save, weight.detach(), gsums, targets[0], targets[1],
+                                    ctx.has_res and ctx.needs_input_grad[3])
+        return dx if ctx.needs_input_grad[0] else None, rets[0], rets[1], dres, None, None, None, None, None
+
+
+def batch_norm_act_ok(x, weight):
+    """Inputs the fused BatchNorm kernels take: bf16 channels-last (N, C, H, W) on the GPU, C a supported width."""
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and weight is not None and weight.dtype == torch.float32
+            and x.is_contiguous(memory_format=torch.channels_last)
+            and _lib.bn_supported(x.shape[0] * x.shape[2] * x.shape[3], x.shape[1]))
+
+
+def batch_norm_act(x, weight, bias, running_mean, running_var, eps, momentum, relu=False, residual=None):
+    if residual is not None and (residual.dtype != x.dtype or residual.shape != x.shape
+                                 or not residual.is_contiguous(memory_format=torch.channels_last)):
+        residual = residual.to(x.dtype).contiguous(memory_format=torch.channels_last)
+    return _BatchNormAct.apply(x, weight, bias, residual, running_mean, running_var, float(eps), float(momentum), bool(relu))
+
+
 class _DropoutAdd(Function):
     @staticmethod
     def forward(ctx, x, identity, p_drop, seed):

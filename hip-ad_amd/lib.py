@@ -46,6 +46,9 @@ SIGNATURES = {
     "hipad_lr_factor": (ctypes.c_float, [c_void_p, c_int]),
     "hipad_keep_mask": (c_int, [c_void_p, ctypes.c_longlong, ctypes.c_float, ctypes.c_uint, c_void_p, c_void_p]),
     "hipad_chunk_mix": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "hipad_bn_supported": (c_int, [ctypes.c_longlong, c_int]),
+    "hipad_bn_forward": (c_int, [c_void_p] * 9 + [ctypes.c_longlong, c_int, ctypes.c_float, ctypes.c_float, c_int, c_void_p]),
+    "hipad_bn_backward": (c_int, [c_void_p] * 10 + [ctypes.c_longlong, c_int, c_void_p]),
     "hipad_grid_mask": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "hipad_dropout_add": (c_int, [c_void_p] * 3 + [ctypes.c_longlong, ctypes.c_float, ctypes.c_uint, c_void_p, c_void_p]),
     "hipad_resample_tables": (c_int, [c_int, c_int, c_void_p, c_void_p]),
@@ -534,6 +537,40 @@ def focal_loss_forward(logits, target, weight, avg_factor, layers, alpha, gamma)
                                           stream_ptr(logits.device))
     check(st, "hipad_focal_loss_forward")
     return loss, grad
+
+
+BN_REPLICAS = 4
+
+
+def bn_supported(rows, channels):
+    return bool(load().hipad_bn_supported(int(rows), int(channels)))
+
+
+def bn_forward(x, residual, gamma, beta, running_mean, running_var, sums, eps, momentum, relu):
+    """x (N, C, H, W) bf16 channels-last -> (y like x, save (2C,) fp32).  ``sums``: zeroed fp32 (BN_REPLICAS * 2C,)."""
+    lib = load()
+    n, c, h, w = x.shape
+    rows = n * h * w
+    y = torch.empty_like(x)           # preserves channels-last
+    save = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.hipad_bn_forward(y.data_ptr(), save.data_ptr(), sums.data_ptr(), x.data_ptr(), _ptr(residual), gamma.data_ptr(),
+                                   beta.data_ptr(), _ptr(running_mean), _ptr(running_var), rows, c, float(eps), float(momentum),
+                                   int(bool(relu)), stream_ptr(x.device)), "hipad_bn_forward")
+    return y, save
+
+
+def bn_backward(dy, y, x, save, gamma, gsums, dgamma, dbeta, need_res):
+    """-> (dx, dres or None), bf16 channels-last like x; dgamma / dbeta (fp32, may be None) are accumulated into."""
+    lib = load()
+    n, c, h, w = x.shape
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if need_res else None
+    with torch.cuda.device(x.device):
+        check(lib.hipad_bn_backward(dx.data_ptr(), _ptr(dres), _ptr(dgamma), _ptr(dbeta), gsums.data_ptr(), dy.data_ptr(), _ptr(y),
+                                    x.data_ptr(), save.data_ptr(), gamma.data_ptr(), n * h * w, c, stream_ptr(x.device)),
+              "hipad_bn_backward")
+    return dx, dres
 
 
 def grid_mask(x, params, use_h, use_w, mode, out_dtype=torch.float32, channels_last=False):

@@ -481,6 +481,31 @@ int hipad_image_finish(float *out, const long long *out_strides, const unsigned 
                        const int *crop_box, int flip, const int *rotate_a, const float *mean, const float *std, int to_rgb,
                        hipad_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Training-mode BatchNorm on bf16 channels-last activations, fused with the identity add and the ReLU that follow it
+ * in a ResNet bottleneck (hip-ad_amd/csrc/batchnorm.hip).  Replaces, per norm layer of the image encoder (mmdet 2.28.2
+ * ResNet / FPN as built by projects/configs/hipad_b2d_stage2.py:112-134 and run by models/sparse_detector.py:66-94),
+ * the library's 3 + 3 BatchNorm launches plus the ReLU (and add) launches by two launches each way.
+ *   x, y, residual, dy, dx, dres: (rows, channels) row-major bf16 = NHWC with rows = N*H*W, 16-byte aligned.
+ *   channels in {64, 128, 256, 512, 1024, 2048} (hipad_bn_supported).
+ *   sums / gsums: HIPAD_BN_REPLICAS x 2 x channels floats, ZERO on entry (partial-sum copies; consumed by the same call).
+ *   save: 2 x channels floats (batch mean, 1 / sqrt(var + eps)) written by the forward for the backward.
+ *   hipad_bn_forward:  y = relu?((x - mean) * rstd * gamma + beta (+ residual)); biased batch variance; when
+ *                      running_mean / running_var are given they are updated in place with `momentum` (unbiased variance),
+ *                      as torch.nn.BatchNorm2d does.
+ *   hipad_bn_backward: dy' = dy gated by y > 0 (y = the forward output; NULL when no ReLU was fused);
+ *                      dx = gamma * rstd * (dy' - mean(dy') - xhat * mean(dy' * xhat)); dres (may be NULL) = dy';
+ *                      dgamma / dbeta (may be NULL) are ACCUMULATED into (+=): pass the parameters' gradient buffers.
+ * ---------------------------------------------------------------------------------- */
+#define HIPAD_BN_REPLICAS 4
+int hipad_bn_supported(long long rows, int channels);
+int hipad_bn_forward(void *y, float *save, float *sums, const void *x, const void *residual, const float *gamma,
+                     const float *beta, float *running_mean, float *running_var, long long rows, int channels, float eps,
+                     float momentum, int relu, hipad_stream_t stream);
+int hipad_bn_backward(void *dx, void *dres, float *dgamma, float *dbeta, float *gsums, const void *dy, const void *y,
+                      const void *x, const float *save, const float *gamma, long long rows, int channels,
+                      hipad_stream_t stream);
+
 /* Tuning knob (host side, process-wide): target number of (point, camera) pairs one
  * wavefront owns in the forward / backward kernels.  <=0 restores the default. */
 void hipad_daf_set_pairs_per_wave(int fwd, int bwd);

@@ -40,6 +40,14 @@ def load_checkpoint(module, path, strict=False, prefix=None):
     return missing, unexpected
 
 
+import os as _os
+
+from hipad_amd import functional as HF
+
+# BatchNorm + identity add + ReLU on the fused kernels (csrc/batchnorm.hip) for bf16 channels-last training inputs
+USE_FUSED_BN = _os.environ.get("HIPAD_FUSED_BN", "1") == "1"
+
+
 class _ShadowWeight(torch.autograd.Function):
     """weight (fp32 master) -> its bf16 copy kept current by the optimiser kernel: no cast launch forward; backward adds
     the bf16 weight gradient straight into the fp32 ``weight.grad`` buffer (one launch, where autocast's cast needs one
@@ -88,12 +96,27 @@ class BatchNorm2d(nn.BatchNorm2d):
     defer_counter = False
     _pending = []
 
-    def forward(self, x):
-        if self.defer_counter and self.training and self.track_running_stats and self.momentum is not None:
+    def forward(self, x, relu=False, residual=None):
+        """``relu`` / ``residual`` (ours): relu?(bn(x) (+ residual)) -- on bf16 channels-last training inputs the whole
+        expression is two launches (hipad_bn_forward), two more in the backward; otherwise the torch ops."""
+        deferred = self.defer_counter and self.training and self.track_running_stats and self.momentum is not None
+        if (self.training and self.track_running_stats and self.momentum is not None and self.affine and USE_FUSED_BN
+                and HF.batch_norm_act_ok(x, self.weight)):
+            if deferred:
+                BatchNorm2d._pending.append(self.num_batches_tracked)
+            else:
+                self.num_batches_tracked.add_(1)
+            return HF.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps, self.momentum,
+                                     relu, residual)
+        if deferred:
             BatchNorm2d._pending.append(self.num_batches_tracked)
-            return nn.functional.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, True,
-                                            self.momentum, self.eps)
-        return super().forward(x)
+            y = nn.functional.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, True,
+                                         self.momentum, self.eps)
+        else:
+            y = super().forward(x)
+        if residual is not None:
+            y = y + residual
+        return nn.functional.relu(y) if relu else y
 
     @staticmethod
     def flush_counters():
@@ -118,17 +141,15 @@ class Bottleneck(nn.Module):
         self.with_cp = with_cp
 
     def _body(self, x):
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
-        return out + (x if self.downsample is None else self.downsample(x))
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.bn2(self.conv2(out), relu=True)
+        identity = x if self.downsample is None else self.downsample(x)
+        return self.bn3(self.conv3(out), relu=True, residual=identity)      # relu(bn3(.) + identity)
 
     def forward(self, x):
         if self.with_cp and x.requires_grad:
-            out = cp.checkpoint(self._body, x, use_reentrant=False)
-        else:
-            out = self._body(x)
-        return self.relu(out)
+            return cp.checkpoint(self._body, x, use_reentrant=False)
+        return self._body(x)
 
 
 class ResNet(BaseModule):
@@ -194,7 +215,7 @@ class ResNet(BaseModule):
                     nn.init.constant_(m.bn3.weight, 0)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(self.bn1(self.conv1(x), relu=True))
         outs = []
         for i, name in enumerate(self.res_layers):
             x = getattr(self, name)(x)

@@ -12,6 +12,7 @@ the pyramid is cast back to fp32 for the aggregation kernels exactly as the refe
 """
 import torch
 
+from hipad_amd import functional as HF
 from hipad_amd.compat import BACKBONES, DETECTORS, HEADS, NECKS, PLUGIN_LAYERS, BaseModule, build_from_cfg
 
 from ..ops import feature_maps_format, shared_feature_grad
@@ -64,6 +65,8 @@ class SparseDetector(BaseModule):
             self.grid_mask.out_channels_last = True
             img = self.grid_mask(img)
         img = img.contiguous(memory_format=torch.channels_last)
+        if img.is_cuda and self.training:
+            HF.BN_ARENA.reset(img.device)        # one fill clears the partial-sum scratch of all norm layers
         with torch.autocast("cuda", dtype=self.encoder_dtype, enabled=img.is_cuda and self.encoder_dtype != torch.float32):
             levels = self.img_backbone(img)
             if self.img_neck is not None:

@@ -160,3 +160,57 @@ def test_grid_mask_kernel_equals_the_torch_construction():
             assert got16.dtype == torch.bfloat16 and got16.is_contiguous(memory_format=torch.channels_last)
             assert torch.equal(got16.cpu(), want.to(torch.bfloat16)), (mode, params)
     assert gm.eval()(x) is x
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,shape,relu,res", [(64, (6, 32, 44), True, False), (256, (6, 16, 22), True, True),
+                                               (2048, (6, 8, 22), True, True), (1024, (2, 5, 7), False, False),
+                                               (128, (1, 3, 1), False, True)])
+def test_fused_batch_norm_add_relu_equals_torch(C, shape, relu, res):
+    """relu(bn(x) + residual) on the fused kernels (bf16 channels-last in / out, fp32 statistics) against torch's
+    batch_norm + add + relu evaluated in fp32 on the same bf16 inputs: output, running statistics, dx, d(residual),
+    d(gamma), d(beta) (accumulated in place into preset gradient buffers)."""
+    from hipad_amd import functional as HF
+    from projects.mmdet3d_plugin.models.image_encoder import BatchNorm2d
+    torch.manual_seed(C)
+    n, h, w = shape
+    bn = BatchNorm2d(C).cuda().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.3)
+    ref = copy_bn = torch.nn.BatchNorm2d(C).cuda().train()
+    copy_bn.load_state_dict(bn.state_dict())
+    x = (torch.randn(n, C, h, w, device="cuda") * 2 + 0.7).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    r = torch.randn(n, C, h, w, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last) if res else None
+    g = torch.randn(n, C, h, w, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x1, r1 = x.clone().requires_grad_(True), (r.clone().requires_grad_(True) if res else None)
+    bn.weight.grad, bn.bias.grad = torch.zeros_like(bn.weight), torch.zeros_like(bn.bias)
+    held = bn.weight.grad
+    HF.BN_ARENA.reset(x.device)
+    assert HF.batch_norm_act_ok(x1, bn.weight)
+    y = bn(x1, relu=relu, residual=r1)
+    assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(g)
+    assert bn.weight.grad is held
+    # fp32 reference on the same (bf16-valued) inputs
+    x2, r2 = x.float().requires_grad_(True), (r.float().requires_grad_(True) if res else None)
+    z = ref(x2)
+    if res:
+        z = z + r2
+    if relu:
+        z = torch.relu(z)
+    z.backward(g.float())
+
+    def close(a, b, tol):
+        a, b = a.float(), b.float()
+        assert float((a - b).norm() / b.norm().clamp_min(1e-12)) < tol, float((a - b).norm() / b.norm().clamp_min(1e-12))
+
+    close(y, z, 4e-3)                       # one bf16 rounding of the output
+    close(x1.grad, x2.grad, 6e-3)
+    if res:
+        close(r1.grad, r2.grad, 4e-3)
+    close(bn.weight.grad, ref.weight.grad, 3e-3)
+    close(bn.bias.grad, ref.bias.grad, 3e-3)
+    close(bn.running_mean, ref.running_mean, 1e-4)
+    close(bn.running_var, ref.running_var, 1e-3)
+    assert int(bn.num_batches_tracked) == 1
