@@ -52,10 +52,12 @@ __device__ __forceinline__ uint4 pack8(const float *f) {
   return u;
 }
 
-// block-level combine of 16 per-thread partials (two 8-channel vectors) over the rows in flight, then one atomic per
-// channel and quantity
+// Block-level combine of the 16 per-thread partials (two 8-channel vectors) over the rows in flight, then one atomic per
+// channel and quantity.  All 256 threads take part: the 2C outputs are dealt over the threads (two threads per output
+// when 2C < 256), so a thread reads at most 16 LDS words -- with only the C / 8 threads of one row doing the sums (first
+// version) a 64-channel layer spent 15 us here.
 __device__ __forceinline__ void combine_and_add(float *__restrict__ gsum, const float *a, const float *b, int tpr, int C,
-                                                float (*sh)[17]) {
+                                                float (*sh)[17], float *sh2) {
   const int tid = threadIdx.x;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -63,17 +65,25 @@ __device__ __forceinline__ void combine_and_add(float *__restrict__ gsum, const 
     sh[tid][8 + k] = b[k];
   }
   __syncthreads();
-  if (tid < tpr) {
-    float acc[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
-    for (int r = tid; r < 256; r += tpr)
-#pragma unroll
-      for (int k = 0; k < 16; ++k) acc[k] += sh[r][k];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      atomicAdd(gsum + tid * 8 + k, acc[k]);
-      atomicAdd(gsum + C + tid * 8 + k, acc[8 + k]);
+  const int rpi = 256 / tpr, outs = 2 * C;
+  if (outs >= 256) {
+    for (int o = tid; o < outs; o += 256) {
+      const int q = o / C, c = o - q * C, lc = c >> 3, k = (c & 7) + 8 * q;
+      float acc = 0.f;
+      for (int lr = 0; lr < rpi; ++lr) acc += sh[lr * tpr + lc][k];
+      atomicAdd(gsum + o, acc);
+    }
+  } else {                       // 2C = 128: two threads per output, each over half of the rows in flight
+    const int o = tid % outs, half = tid / outs, parts = 256 / outs;
+    const int q = o / C, c = o - q * C, lc = c >> 3, k = (c & 7) + 8 * q;
+    const int per = rpi / parts;
+    float acc = 0.f;
+    for (int lr = half * per; lr < (half + 1) * per; ++lr) acc += sh[lr * tpr + lc][k];
+    sh2[tid] = acc;
+    __syncthreads();
+    if (tid < outs) {
+      for (int p = 1; p < parts; ++p) acc += sh2[tid + p * outs];
+      atomicAdd(gsum + o, acc);
     }
   }
 }
@@ -81,6 +91,7 @@ __device__ __forceinline__ void combine_and_add(float *__restrict__ gsum, const 
 __global__ __launch_bounds__(256) void bn_stats_kernel(float *__restrict__ sums, const uint4 *__restrict__ x, long rows, int C,
                                                        long rows_per_block) {
   __shared__ float sh[256][17];
+  __shared__ float sh2[256];
   const int tpr = C >> 3, rpi = 256 / tpr;
   const int lc = threadIdx.x % tpr, lr = threadIdx.x / tpr;
   const long r0 = (long)blockIdx.x * rows_per_block;
@@ -110,7 +121,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(float *__restrict__ sums,
       }
     }
   }
-  combine_and_add(sums + (blockIdx.x % kReplicas) * 2 * C, s, ss, tpr, C, sh);
+  combine_and_add(sums + (blockIdx.x % kReplicas) * 2 * C, s, ss, tpr, C, sh, sh2);
 }
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(uint4 *__restrict__ y, const uint4 *__restrict__ x,
@@ -122,28 +133,41 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(uint4 *__restrict__ y, co
   const int tpr = C >> 3, rpi = 256 / tpr;
   const int lc = threadIdx.x % tpr, lr = threadIdx.x / tpr;
   const float inv_m = 1.f / (float)rows;
-  float scale[8], shift[8];
+  // all prologue loads are issued before anything waits: a branch inside this loop (first version: the first workgroup's
+  // stores) made every channel a separate memory round trip -- 27 us per launch instead of 7
+  float scale[8], shift[8], mean_[8], var_[8], s1[8], s2[8], gm[8], bt[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int c = lc * 8 + k;
-    float s1 = 0.f, s2 = 0.f;
+    s1[k] = s2[k] = 0.f;
 #pragma unroll
     for (int rep = 0; rep < kReplicas; ++rep) {
-      s1 += sums[rep * 2 * C + c];
-      s2 += sums[rep * 2 * C + C + c];
+      s1[k] += sums[rep * 2 * C + c];
+      s2[k] += sums[rep * 2 * C + C + c];
     }
-    const float mean = s1 * inv_m;
-    float var = s2 * inv_m - mean * mean;
+    gm[k] = gamma[c];
+    bt[k] = beta[c];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float mean = s1[k] * inv_m;
+    float var = s2[k] * inv_m - mean * mean;
     var = var > 0.f ? var : 0.f;
     const float rstd = rsqrtf(var + eps);
-    scale[k] = gamma[c] * rstd;
-    shift[k] = beta[c] - mean * scale[k];
-    if (blockIdx.x == 0 && lr == 0) {
-      save[c] = mean;
-      save[C + c] = rstd;
+    scale[k] = gm[k] * rstd;
+    shift[k] = bt[k] - mean * scale[k];
+    mean_[k] = mean;
+    var_[k] = var;
+  }
+  if (blockIdx.x == 0 && lr == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = lc * 8 + k;
+      save[c] = mean_[k];
+      save[C + c] = rsqrtf(var_[k] + eps);
       if (running_mean) {
-        const float unbiased = rows > 1 ? var * ((float)rows / (float)(rows - 1)) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        const float unbiased = rows > 1 ? var_[k] * ((float)rows / (float)(rows - 1)) : var_[k];
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean_[k];
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
       }
     }
@@ -151,24 +175,35 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(uint4 *__restrict__ y, co
   const long r0 = (long)blockIdx.x * rows_per_block;
   long r1 = r0 + rows_per_block;
   if (r1 > rows) r1 = rows;
-  for (long r = r0 + lr; r < r1; r += rpi) {
-    const long i = r * tpr + lc;
-    float f[8], o[8];
-    unpack8(x[i], f);
-    if (residual) {
-      float g[8];
-      unpack8(residual[i], g);
+  for (long r = r0 + lr; r < r1; r += (long)kUnroll * rpi) {
+    uint4 vx[kUnroll], vr[kUnroll];
+    bool ok[kUnroll];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) o[k] = f[k] * scale[k] + shift[k] + g[k];
-    } else {
+    for (int j = 0; j < kUnroll; ++j) {
+      const long rr = r + (long)j * rpi;
+      ok[j] = rr < r1;
+      const long i = (ok[j] ? rr : r) * tpr + lc;
+      vx[j] = x[i];
+      if (residual) vr[j] = residual[i];     // uniform branch
+    }
+#pragma unroll
+    for (int j = 0; j < kUnroll; ++j) {
+      float f[8], o[8];
+      unpack8(vx[j], f);
 #pragma unroll
       for (int k = 0; k < 8; ++k) o[k] = f[k] * scale[k] + shift[k];
-    }
-    if (relu) {
+      if (residual) {
+        float g[8];
+        unpack8(vr[j], g);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) o[k] = o[k] > 0.f ? o[k] : 0.f;
+        for (int k = 0; k < 8; ++k) o[k] += g[k];
+      }
+      if (relu) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = o[k] > 0.f ? o[k] : 0.f;
+      }
+      if (ok[j]) y[(r + (long)j * rpi) * tpr + lc] = pack8(o);
     }
-    y[i] = pack8(o);
   }
 }
 
@@ -177,6 +212,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(float *__restrict__ 
                                                             const uint4 *__restrict__ x, const float *__restrict__ save,
                                                             long rows, int C, long rows_per_block) {
   __shared__ float sh[256][17];
+  __shared__ float sh2[256];
   const int tpr = C >> 3, rpi = 256 / tpr;
   const int lc = threadIdx.x % tpr, lr = threadIdx.x / tpr;
   float mean[8], rstd[8], s[8], sx[8];
@@ -220,7 +256,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(float *__restrict__ 
       }
     }
   }
-  combine_and_add(gsums + (blockIdx.x % kReplicas) * 2 * C, s, sx, tpr, C, sh);
+  combine_and_add(gsums + (blockIdx.x % kReplicas) * 2 * C, s, sx, tpr, C, sh, sh2);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(uint4 *__restrict__ dx, uint4 *__restrict__ dres /* may be NULL */,
@@ -232,44 +268,68 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(uint4 *__restrict__ d
   const int tpr = C >> 3, rpi = 256 / tpr;
   const int lc = threadIdx.x % tpr, lr = threadIdx.x / tpr;
   const float inv_m = 1.f / (float)rows;
-  float mean[8], rstd[8], a[8], b[8], gr[8];
+  float mean[8], rstd[8], a[8], b[8], gr[8], sdy[8], sdyx[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
+  for (int k = 0; k < 8; ++k) {           // loads only (no branch in here, see bn_apply_kernel)
     const int c = lc * 8 + k;
     mean[k] = save[c];
     rstd[k] = save[C + c];
-    float sdy = 0.f, sdyx = 0.f;
+    sdy[k] = sdyx[k] = 0.f;
 #pragma unroll
     for (int rep = 0; rep < kReplicas; ++rep) {
-      sdy += gsums[rep * 2 * C + c];
-      sdyx += gsums[rep * 2 * C + C + c];
+      sdy[k] += gsums[rep * 2 * C + c];
+      sdyx[k] += gsums[rep * 2 * C + C + c];
     }
-    a[k] = sdy * inv_m;
-    b[k] = sdyx * inv_m;
-    gr[k] = gamma[c] * rstd[k];
-    if (blockIdx.x == 0 && lr == 0) {   // single writer per channel: accumulate into the parameter gradients
-      if (dgamma) dgamma[c] += sdyx;
-      if (dbeta) dbeta[c] += sdy;
+    gr[k] = gamma[c];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    a[k] = sdy[k] * inv_m;
+    b[k] = sdyx[k] * inv_m;
+    gr[k] *= rstd[k];
+  }
+  if (blockIdx.x == 0 && lr == 0) {         // single writer per channel: accumulate into the parameter gradients
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = lc * 8 + k;
+      if (dgamma) dgamma[c] += sdyx[k];
+      if (dbeta) dbeta[c] += sdy[k];
     }
   }
   const long r0 = (long)blockIdx.x * rows_per_block;
   long r1 = r0 + rows_per_block;
   if (r1 > rows) r1 = rows;
-  for (long r = r0 + lr; r < r1; r += rpi) {
-    const long i = r * tpr + lc;
-    float g[8], f[8], o[8];
-    unpack8(dy[i], g);
-    unpack8(x[i], f);
-    if (y) {
-      float yy[8];
-      unpack8(y[i], yy);
+  for (long r = r0 + lr; r < r1; r += (long)kUnroll * rpi) {
+    uint4 vg[kUnroll], vx[kUnroll], vy[kUnroll];
+    bool ok[kUnroll];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) g[k] = yy[k] > 0.f ? g[k] : 0.f;
+    for (int j = 0; j < kUnroll; ++j) {
+      const long rr = r + (long)j * rpi;
+      ok[j] = rr < r1;
+      const long i = (ok[j] ? rr : r) * tpr + lc;
+      vg[j] = dy[i];
+      vx[j] = x[i];
+      if (y) vy[j] = y[i];
     }
-    if (dres) dres[i] = pack8(g);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) o[k] = gr[k] * (g[k] - a[k] - (f[k] - mean[k]) * rstd[k] * b[k]);
-    dx[i] = pack8(o);
+    for (int j = 0; j < kUnroll; ++j) {
+      float g[8], f[8], o[8];
+      unpack8(vg[j], g);
+      unpack8(vx[j], f);
+      if (y) {
+        float yy[8];
+        unpack8(vy[j], yy);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g[k] = yy[k] > 0.f ? g[k] : 0.f;
+      }
+      const long i = (r + (long)j * rpi) * tpr + lc;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = gr[k] * (g[k] - a[k] - (f[k] - mean[k]) * rstd[k] * b[k]);
+      if (ok[j]) {
+        if (dres) dres[i] = pack8(g);
+        dx[i] = pack8(o);
+      }
+    }
   }
 }
 
@@ -281,8 +341,10 @@ static inline bool bn_shape_ok(long rows, int C) {
 
 static inline void bn_grid(long rows, int C, unsigned *blocks, long *rows_per_block) {
   const int rpi = 256 / (C >> 3);
-  const long per_iter = (long)rpi * kUnroll;
-  long want = (rows + per_iter - 1) / per_iter;   // at least one full iteration per workgroup
+  // at least one full unrolled iteration per workgroup; two for wide layers, whose per-workgroup fixed cost (the 2C-entry
+  // prologue reads and 2C atomics) is as large as one iteration's data
+  const long per_iter = (long)rpi * kUnroll * (C >= 512 ? 2 : 1);
+  long want = (rows + per_iter - 1) / per_iter;
   if (want > 1024) want = 1024;
   long rpb = (rows + want - 1) / want;
   rpb = (rpb + rpi - 1) / rpi * rpi;
