@@ -129,8 +129,9 @@ def test_shadow_weight_convolution_equals_autocast_cast():
         assert conv.weight.grad is held and id(conv.weight) in HF.INPLACE_PARAMS      # accumulated in place
         # same operands, but MIOpen may pick another solver on the second call of a shape (different summation order):
         # bf16-rounding-level agreement, not bitwise
-        for a, b in ((y0, y1), (gx0, x.grad), (gw0, conv.weight.grad)):
-            assert float((a.float() - b.float()).norm() / b.float().norm()) < 5e-3
+        # (the weight gradient is a bf16 tensor out of a long reduction: two solvers measured 0.9 % apart)
+        for a, b, tol in ((y0, y1, 5e-3), (gx0, x.grad, 5e-3), (gw0, conv.weight.grad, 2e-2)):
+            assert float((a.float() - b.float()).norm() / b.float().norm()) < tol
         # outside autocast (fp32 run) the module is a plain nn.Conv2d
         y2 = conv(x.detach())
         assert y2.dtype == torch.float32
