@@ -6,7 +6,7 @@ import _trace
 # usage: trace_categories.py <dir> <window_ms> <steps>   (last window_ms of the trace, divided by `steps`)
 #    or: trace_categories.py <dir> steps <n> [skip_last]  (EXACTLY the last n optimiser-delimited steps)
 EXACT = sys.argv[2] == "steps"
-CATS = [("encoder (MIOpen conv/BN, bf16 elementwise)", r"igemm|ck::|_ZN2ck|MIOpen|SubTensorOp|BFloat16|bfloat16|max_pool|batch_norm|upsample|Bf16|threshold"),
+CATS = [("encoder (MIOpen / CK conv, hipad BatchNorm, bf16 elementwise)", r"igemm|ck::|_ZN2ck|MIOpen|SubTensorOp|BFloat16|bfloat16|max_pool|batch_norm|upsample|Bf16|threshold|hipad::bn_|hipad::grid_mask"),
         ("linear (hipad gemm, fused backward)", r"hipad::gemm|hipad::linear_"),
         ("MLP chains (hipad chain fwd / bwd / dW, operand pack)", r"hipad::chain_|hipad::pack_weights"),
         ("aggregation (daf, weights softmax, projection)", r"hipad::daf|hipad::weights_softmax|hipad::project|hipad::fill_zero|hipad::proj"),
