@@ -55,9 +55,9 @@ int fill_zero(void *ptr, size_t bytes, hipStream_t stream) {
 // LT = compile-time number of levels (0 = runtime).  GEO: (height, width, first row) of every (camera, level) held in
 // lanes 0..cams*L-1 and read back with v_readlane -- no scalar memory load between a pair's coordinates and its row
 // loads (needs cams*L <= 64).
-template <int LT, bool GEO>
+template <int LT, bool GEO, typename FT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void daf_fwd_c256_kernel(
-    float *__restrict__ dst, const float *__restrict__ feat, const int *__restrict__ ss,
+    float *__restrict__ dst, const FT *__restrict__ feat, const int *__restrict__ ss,
     const int *__restrict__ start, const float *__restrict__ loc, const float *__restrict__ wts,
     int n_items, int nchunks, int ppc, int cams, int num_feat, int L_rt, int A, int P, int G) {
   const int lane = threadIdx.x & (kWave - 1);
@@ -107,14 +107,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
         const int h0 = max(t.h_low, 0), h1 = min(t.h_low + 1, H - 1);
         const int w0 = max(t.w_low, 0), w1 = min(t.w_low + 1, W - 1);
         const size_t base = frow0 + (size_t)(GEO ? rl_i(geoS, cs) : start[cs]);
-        const float4 *r00 = reinterpret_cast<const float4 *>(feat + (base + (size_t)uni(h0 * W + w0)) * 256) + lane;
-        const float4 *r01 = reinterpret_cast<const float4 *>(feat + (base + (size_t)uni(h0 * W + w1)) * 256) + lane;
-        const float4 *r10 = reinterpret_cast<const float4 *>(feat + (base + (size_t)uni(h1 * W + w0)) * 256) + lane;
-        const float4 *r11 = reinterpret_cast<const float4 *>(feat + (base + (size_t)uni(h1 * W + w1)) * 256) + lane;
-        const float4 v1 = sel4(t.in_h0 && t.in_w0, *r00);
-        const float4 v2 = sel4(t.in_h0 && t.in_w1, *r01);
-        const float4 v3 = sel4(t.in_h1 && t.in_w0, *r10);
-        const float4 v4 = sel4(t.in_h1 && t.in_w1, *r11);
+        const float4 v1 = sel4(t.in_h0 && t.in_w0, load_row4<FT>(feat, base + (size_t)uni(h0 * W + w0), lane));
+        const float4 v2 = sel4(t.in_h0 && t.in_w1, load_row4<FT>(feat, base + (size_t)uni(h0 * W + w1), lane));
+        const float4 v3 = sel4(t.in_h1 && t.in_w0, load_row4<FT>(feat, base + (size_t)uni(h1 * W + w0), lane));
+        const float4 v4 = sel4(t.in_h1 && t.in_w1, load_row4<FT>(feat, base + (size_t)uni(h1 * W + w1), lane));
         const float aw = wrow[s * G];
         const float w1c = t.hh * t.hw, w2c = t.hh * t.lw, w3c = t.lh * t.hw, w4c = t.lh * t.lw;
         acc.x += aw * (w1c * v1.x + w2c * v2.x + w3c * v3.x + w4c * v4.x);
@@ -546,13 +542,15 @@ size_t hipad_daf_forward_workspace(int bs, int cams, int num_feat, int C, int L,
   return (size_t)bs * A * pl.nchunks * C * sizeof(float);
 }
 
-int hipad_daf_forward(float *out, const float *feat, const int32_t *spatial_shape,
-                      const int32_t *scale_start_index, const float *loc, const float *weights,
-                      int bs, int cams, int num_feat, int C, int L, int A, int P, int G,
-                      void *workspace, size_t workspace_bytes, hipad_stream_t stream_) {
+static int daf_forward_impl(float *out, const void *feat_, bool feat_bf16, const int32_t *spatial_shape,
+                            const int32_t *scale_start_index, const float *loc, const float *weights,
+                            int bs, int cams, int num_feat, int C, int L, int A, int P, int G,
+                            void *workspace, size_t workspace_bytes, hipad_stream_t stream_) {
   int rc = check_dims(bs, cams, num_feat, C, L, A, P, G);
   if (rc != HIPAD_OK) return rc;
-  if (!out || !feat || !spatial_shape || !scale_start_index || !loc || !weights) return HIPAD_EINVAL;
+  if (!out || !feat_ || !spatial_shape || !scale_start_index || !loc || !weights) return HIPAD_EINVAL;
+  const float *feat = (const float *)feat_;
+  if (feat_bf16 && !((C == 256) && ((C / G) % 4 == 0))) return HIPAD_EINVAL;   // bf16 rows: the 256-channel kernel only
   hipStream_t stream = (hipStream_t)stream_;
   const Plan pl = make_plan(P, cams, g_pairs_fwd, (long)bs * A);
   const int n_anchor = bs * A;
@@ -566,10 +564,14 @@ int hipad_daf_forward(float *out, const float *feat, const int32_t *spatial_shap
   const bool fast = (C == 256) && ((C / G) % 4 == 0);
   if (fast) {
     const int blocks = (n_items + 3) / 4;
-#define HIPAD_FWD(LT, GEO)                                                                                  \
-  hipLaunchKernelGGL((daf_fwd_c256_kernel<LT, GEO>), dim3(blocks), dim3(256), 0, stream, dst, feat,         \
-                     spatial_shape, scale_start_index, loc, weights, n_items, pl.nchunks, pl.ppc, cams,     \
-                     num_feat, L, A, P, G)
+#define HIPAD_FWD_T(LT, GEO, FT)                                                                            \
+  hipLaunchKernelGGL((daf_fwd_c256_kernel<LT, GEO, FT>), dim3(blocks), dim3(256), 0, stream, dst,           \
+                     (const FT *)feat_, spatial_shape, scale_start_index, loc, weights, n_items, pl.nchunks, \
+                     pl.ppc, cams, num_feat, L, A, P, G)
+#define HIPAD_FWD(LT, GEO)                                                              \
+  do {                                                                                  \
+    if (feat_bf16) HIPAD_FWD_T(LT, GEO, uint16_t); else HIPAD_FWD_T(LT, GEO, float);    \
+  } while (0)
     const bool geo = cams * L <= kWave;
     if (L == 4) {
       if (geo) HIPAD_FWD(4, true); else HIPAD_FWD(4, false);
@@ -579,6 +581,7 @@ int hipad_daf_forward(float *out, const float *feat, const int32_t *spatial_shap
       if (geo) HIPAD_FWD(0, true); else HIPAD_FWD(0, false);
     }
 #undef HIPAD_FWD
+#undef HIPAD_FWD_T
     if (pl.nchunks > 1) {
       const int n = n_anchor * 64;
       hipLaunchKernelGGL(daf_fwd_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, out,
@@ -606,14 +609,15 @@ size_t hipad_daf_backward_workspace(int bs, int cams, int num_feat, int C, int L
   return daf_bwd_sorted_workspace(d);
 }
 
-int hipad_daf_backward(const float *feat, const int32_t *spatial_shape,
-                       const int32_t *scale_start_index, const float *loc, const float *weights,
-                       const float *grad_out, float *grad_feat, float *grad_loc, float *grad_w,
-                       int bs, int cams, int num_feat, int C, int L, int A, int P, int G, int flags,
-                       void *workspace, size_t workspace_bytes, hipad_stream_t stream_) {
+static int daf_backward_impl(const void *feat_, bool feat_bf16, const int32_t *spatial_shape,
+                             const int32_t *scale_start_index, const float *loc, const float *weights,
+                             const float *grad_out, float *grad_feat, float *grad_loc, float *grad_w,
+                             int bs, int cams, int num_feat, int C, int L, int A, int P, int G, int flags,
+                             void *workspace, size_t workspace_bytes, hipad_stream_t stream_) {
   int rc = check_dims(bs, cams, num_feat, C, L, A, P, G);
   if (rc != HIPAD_OK) return rc;
-  if (!feat || !spatial_shape || !scale_start_index || !loc || !weights || !grad_out) return HIPAD_EINVAL;
+  if (!feat_ || !spatial_shape || !scale_start_index || !loc || !weights || !grad_out) return HIPAD_EINVAL;
+  const float *feat = (const float *)feat_;
   if (flags & ~(HIPAD_DAF_OVERWRITE_LOC_W | HIPAD_DAF_ATOMIC_FEAT)) return HIPAD_EINVAL;
   if (!grad_feat && !grad_loc && !grad_w) return HIPAD_OK;
   hipStream_t stream = (hipStream_t)stream_;
@@ -622,6 +626,7 @@ int hipad_daf_backward(const float *feat, const int32_t *spatial_shape,
   const bool overwrite = (flags & HIPAD_DAF_OVERWRITE_LOC_W) != 0;
   const DafDims d{bs, cams, num_feat, C, L, A, P, G};
   const bool fast = (C == 256) && (G == 8);
+  if (feat_bf16 && !(fast && !(flags & HIPAD_DAF_ATOMIC_FEAT) && daf_bwd_sorted_supported(d))) return HIPAD_EINVAL;
   if (fast && !(flags & HIPAD_DAF_ATOMIC_FEAT) && daf_bwd_sorted_supported(d)) {
     // sorted path: grad_feat by row-sorted gather, grad_loc / grad_w by the wave-per-item kernel
     if (grad_feat) {
@@ -630,7 +635,7 @@ int hipad_daf_backward(const float *feat, const int32_t *spatial_shape,
       if (rc != HIPAD_OK) return rc;
     }
     if (grad_loc || grad_w) {
-      rc = daf_bwd_lw(feat, spatial_shape, scale_start_index, loc, weights, grad_out, grad_loc, grad_w, d,
+      rc = daf_bwd_lw(feat_, feat_bf16, spatial_shape, scale_start_index, loc, weights, grad_out, grad_loc, grad_w, d,
                       pl.nchunks, pl.ppc, overwrite, stream);
       if (rc != HIPAD_OK) return rc;
     }
@@ -664,6 +669,40 @@ int hipad_daf_backward(const float *feat, const int32_t *spatial_shape,
                        cblocks);
   }
   return launch_status();
+}
+
+int hipad_daf_forward(float *out, const float *feat, const int32_t *spatial_shape,
+                      const int32_t *scale_start_index, const float *loc, const float *weights,
+                      int bs, int cams, int num_feat, int C, int L, int A, int P, int G,
+                      void *workspace, size_t workspace_bytes, hipad_stream_t stream) {
+  return daf_forward_impl(out, feat, false, spatial_shape, scale_start_index, loc, weights, bs, cams, num_feat, C, L, A, P, G,
+                          workspace, workspace_bytes, stream);
+}
+
+int hipad_daf_forward_bf16(float *out, const void *feat_bf16, const int32_t *spatial_shape,
+                           const int32_t *scale_start_index, const float *loc, const float *weights,
+                           int bs, int cams, int num_feat, int C, int L, int A, int P, int G,
+                           void *workspace, size_t workspace_bytes, hipad_stream_t stream) {
+  return daf_forward_impl(out, feat_bf16, true, spatial_shape, scale_start_index, loc, weights, bs, cams, num_feat, C, L, A, P,
+                          G, workspace, workspace_bytes, stream);
+}
+
+int hipad_daf_backward(const float *feat, const int32_t *spatial_shape,
+                       const int32_t *scale_start_index, const float *loc, const float *weights,
+                       const float *grad_out, float *grad_feat, float *grad_loc, float *grad_w,
+                       int bs, int cams, int num_feat, int C, int L, int A, int P, int G, int flags,
+                       void *workspace, size_t workspace_bytes, hipad_stream_t stream) {
+  return daf_backward_impl(feat, false, spatial_shape, scale_start_index, loc, weights, grad_out, grad_feat, grad_loc, grad_w,
+                           bs, cams, num_feat, C, L, A, P, G, flags, workspace, workspace_bytes, stream);
+}
+
+int hipad_daf_backward_bf16(const void *feat_bf16, const int32_t *spatial_shape,
+                            const int32_t *scale_start_index, const float *loc, const float *weights,
+                            const float *grad_out, float *grad_feat, float *grad_loc, float *grad_w,
+                            int bs, int cams, int num_feat, int C, int L, int A, int P, int G, int flags,
+                            void *workspace, size_t workspace_bytes, hipad_stream_t stream) {
+  return daf_backward_impl(feat_bf16, true, spatial_shape, scale_start_index, loc, weights, grad_out, grad_feat, grad_loc,
+                           grad_w, bs, cams, num_feat, C, L, A, P, G, flags, workspace, workspace_bytes, stream);
 }
 
 int hipad_daf_taps(uint8_t *valid, int32_t *taps, const int32_t *spatial_shape,

@@ -355,9 +355,9 @@ __device__ __forceinline__ float group8_sum(float v) { return oct_sum(v); }
 // v_readlane, so the pair loop has no scalar memory load between a pair's coordinates and its 16 row loads.  The loop
 // body is branch-free (null gw / gloc only skip the final stores): with uniform branches between the levels the
 // compiler kept each level's loads behind the previous level's reduction, four memory latencies per pair instead of one.
-template <int LT, bool OVERWRITE, bool GEO>
+template <int LT, bool OVERWRITE, bool GEO, typename FT>
 __global__ __launch_bounds__(256) void daf_bwd_lw_kernel(
-    const float *__restrict__ feat, const int *__restrict__ ss, const int *__restrict__ start,
+    const FT *__restrict__ feat, const int *__restrict__ ss, const int *__restrict__ start,
     const float *__restrict__ loc, const float *__restrict__ wts, const float *__restrict__ gout,
     float *__restrict__ gloc, float *__restrict__ gw, int n_items, int nchunks, int ppc, int cams,
     int num_feat, int L_rt, int A, int P) {
@@ -434,14 +434,10 @@ __global__ __launch_bounds__(256) void daf_bwd_lw_kernel(
         const int h0 = max(t.h_low, 0), h1 = min(t.h_low + 1, H - 1);
         const int w0 = max(t.w_low, 0), w1 = min(t.w_low + 1, W - 1);
         const size_t base = frow0 + (size_t)(GEO ? rl_i(geoS, cs) : start[cs]);
-        const float4 *r00 = reinterpret_cast<const float4 *>(feat + (base + (size_t)uni(h0 * W + w0)) * 256) + lane;
-        const float4 *r01 = reinterpret_cast<const float4 *>(feat + (base + (size_t)uni(h0 * W + w1)) * 256) + lane;
-        const float4 *r10 = reinterpret_cast<const float4 *>(feat + (base + (size_t)uni(h1 * W + w0)) * 256) + lane;
-        const float4 *r11 = reinterpret_cast<const float4 *>(feat + (base + (size_t)uni(h1 * W + w1)) * 256) + lane;
-        const float4 v1 = sel4(t.in_h0 && t.in_w0, *r00);
-        const float4 v2 = sel4(t.in_h0 && t.in_w1, *r01);
-        const float4 v3 = sel4(t.in_h1 && t.in_w0, *r10);
-        const float4 v4 = sel4(t.in_h1 && t.in_w1, *r11);
+        const float4 v1 = sel4(t.in_h0 && t.in_w0, load_row4<FT>(feat, base + (size_t)uni(h0 * W + w0), lane));
+        const float4 v2 = sel4(t.in_h0 && t.in_w1, load_row4<FT>(feat, base + (size_t)uni(h0 * W + w1), lane));
+        const float4 v3 = sel4(t.in_h1 && t.in_w0, load_row4<FT>(feat, base + (size_t)uni(h1 * W + w0), lane));
+        const float4 v4 = sel4(t.in_h1 && t.in_w1, load_row4<FT>(feat, base + (size_t)uni(h1 * W + w1), lane));
         const float aw = LT ? awl[LT ? s : 0] : wbase[wofs + s * G];
         const float w1c = t.hh * t.hw, w2c = t.hh * t.lw, w3c = t.lh * t.hw, w4c = t.lh * t.lw;
         // value, d/dh, d/dw per channel (cu:92-118), dotted with grad_out
@@ -552,15 +548,19 @@ int daf_bwd_sorted_feat(const float *, const int *ss, const int *start, const fl
   return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
 }
 
-int daf_bwd_lw(const float *feat, const int *ss, const int *start, const float *loc, const float *wts,
+int daf_bwd_lw(const void *feat, bool feat_bf16, const int *ss, const int *start, const float *loc, const float *wts,
                const float *gout, float *gloc, float *gw, const DafDims &d, int nchunks, int ppc,
                bool overwrite, hipStream_t stream) {
   const int n_items = d.bs * d.A * nchunks;
   const int blocks = (n_items + 3) / 4;
-#define HIPAD_LW(LT, OW, GEO)                                                                         \
-  hipLaunchKernelGGL((daf_bwd_lw_kernel<LT, OW, GEO>), dim3(blocks), dim3(256), 0, stream, feat, ss,  \
-                     start, loc, wts, gout, gloc, gw, n_items, nchunks, ppc, d.cams, d.num_feat,      \
-                     d.L, d.A, d.P)
+#define HIPAD_LW_T(LT, OW, GEO, FT)                                                                       \
+  hipLaunchKernelGGL((daf_bwd_lw_kernel<LT, OW, GEO, FT>), dim3(blocks), dim3(256), 0, stream,            \
+                     (const FT *)feat, ss, start, loc, wts, gout, gloc, gw, n_items, nchunks, ppc, d.cams, \
+                     d.num_feat, d.L, d.A, d.P)
+#define HIPAD_LW(LT, OW, GEO)                                                      \
+  do {                                                                             \
+    if (feat_bf16) HIPAD_LW_T(LT, OW, GEO, uint16_t); else HIPAD_LW_T(LT, OW, GEO, float); \
+  } while (0)
   const bool geo = d.cams * d.L <= kWave;
   if (d.L == 4 && geo) {
     if (overwrite) HIPAD_LW(4, true, true); else HIPAD_LW(4, false, true);
@@ -572,6 +572,7 @@ int daf_bwd_lw(const float *feat, const int *ss, const int *start, const float *
     if (overwrite) HIPAD_LW(0, true, false); else HIPAD_LW(0, false, false);
   }
 #undef HIPAD_LW
+#undef HIPAD_LW_T
   return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
 }
 

@@ -48,6 +48,21 @@ __device__ __forceinline__ Taps make_taps(float loc_h, float loc_w, int H, int W
   return t;
 }
 
+// One 256-channel pyramid row, 4 channels per lane: fp32 rows are 1 KiB (one dwordx4 per lane), bf16 rows 512 B (one
+// dwordx2 per lane, widened in registers -- exact, the values ARE bf16: the encoder's output dtype).
+template <typename FT>
+__device__ __forceinline__ float4 load_row4(const FT *__restrict__ feat, size_t row, int lane);
+template <>
+__device__ __forceinline__ float4 load_row4<float>(const float *__restrict__ feat, size_t row, int lane) {
+  return *(reinterpret_cast<const float4 *>(feat + row * 256) + lane);
+}
+template <>
+__device__ __forceinline__ float4 load_row4<uint16_t>(const uint16_t *__restrict__ feat, size_t row, int lane) {
+  const uint2 u = *(reinterpret_cast<const uint2 *>(feat + row * 256) + lane);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xFFFF0000u));
+}
+
 __device__ __forceinline__ float4 sel4(bool c, float4 v) {
   return c ? v : make_float4(0.f, 0.f, 0.f, 0.f);
 }
@@ -91,7 +106,7 @@ int daf_bwd_sorted_feat(const float *feat_unused, const int *ss, const int *star
                         void *workspace, size_t workspace_bytes, hipStream_t stream);
 
 // grad_loc / grad_w by one wave per (anchor, chunk of points); no atomics
-int daf_bwd_lw(const float *feat, const int *ss, const int *start, const float *loc, const float *wts,
+int daf_bwd_lw(const void *feat, bool feat_bf16, const int *ss, const int *start, const float *loc, const float *wts,
                const float *gout, float *gloc, float *gw, const DafDims &d, int nchunks, int ppc,
                bool overwrite, hipStream_t stream);
 

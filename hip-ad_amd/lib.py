@@ -20,6 +20,8 @@ SIGNATURES = {
     "hipad_daf_set_pairs_per_wave": (None, [c_int, c_int]),
     "hipad_daf_forward_workspace": (c_size_t, [c_int] * 8),
     "hipad_daf_forward": (c_int, [c_void_p] * 6 + [c_int] * 8 + [c_void_p, c_size_t, c_void_p]),
+    "hipad_daf_forward_bf16": (c_int, [c_void_p] * 6 + [c_int] * 8 + [c_void_p, c_size_t, c_void_p]),
+    "hipad_daf_backward_bf16": (c_int, [c_void_p] * 9 + [c_int] * 8 + [c_int, c_void_p, c_size_t, c_void_p]),
     "hipad_daf_backward_workspace": (c_size_t, [c_int] * 8),
     "hipad_daf_backward": (c_int, [c_void_p] * 9 + [c_int] * 8 + [c_int, c_void_p, c_size_t, c_void_p]),
     "hipad_daf_taps": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
@@ -150,7 +152,8 @@ def _workspace(nbytes, device):
 
 def daf_forward(feat, spatial_shape, scale_start_index, loc, weights, out=None):
     lib = load()
-    _req(feat, torch.float32, "feat"); _req(loc, torch.float32, "sampling_location")
+    bf16 = feat.dtype == torch.bfloat16        # the encoder's own rows: hipad_daf_forward_bf16 (same values, half the bytes)
+    _req(feat, torch.bfloat16 if bf16 else torch.float32, "feat"); _req(loc, torch.float32, "sampling_location")
     _req(weights, torch.float32, "weights"); _req(spatial_shape, torch.int32, "spatial_shape")
     _req(scale_start_index, torch.int32, "scale_start_index")
     d = daf_dims(feat, spatial_shape, loc, weights)
@@ -160,7 +163,7 @@ def daf_forward(feat, spatial_shape, scale_start_index, loc, weights, out=None):
     nbytes = lib.hipad_daf_forward_workspace(*d)
     ws = _workspace(nbytes, feat.device) if nbytes else None
     with torch.cuda.device(feat.device):
-        st = lib.hipad_daf_forward(out.data_ptr(), feat.data_ptr(), spatial_shape.data_ptr(),
+        st = (lib.hipad_daf_forward_bf16 if bf16 else lib.hipad_daf_forward)(out.data_ptr(), feat.data_ptr(), spatial_shape.data_ptr(),
                                    scale_start_index.data_ptr(), loc.data_ptr(), weights.data_ptr(), *d,
                                    ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
                                    stream_ptr(feat.device))
@@ -180,8 +183,11 @@ def daf_backward(feat, spatial_shape, scale_start_index, loc, weights, grad_out,
     flags = (1 if overwrite_loc_w else 0) | (2 if atomic_feat else 0)
     nbytes = 0 if (atomic_feat or grad_feat is None) else lib.hipad_daf_backward_workspace(*d)
     ws = _workspace(nbytes, feat.device) if nbytes else None
+    bf16 = feat.dtype == torch.bfloat16
+    if bf16 and atomic_feat:
+        raise HipadError("daf_backward: bf16 feature rows have no atomic-scatter variant")
     with torch.cuda.device(feat.device):
-        st = lib.hipad_daf_backward(
+        st = (lib.hipad_daf_backward_bf16 if bf16 else lib.hipad_daf_backward)(
             feat.data_ptr(), spatial_shape.data_ptr(), scale_start_index.data_ptr(), loc.data_ptr(),
             weights.data_ptr(), grad_out.data_ptr(),
             grad_feat.data_ptr() if grad_feat is not None else None,

@@ -103,6 +103,24 @@ int hipad_daf_backward(const float *feat, const int32_t *spatial_shape,
                        int num_anchors, int num_pts, int num_groups, int flags, void *workspace,
                        size_t workspace_bytes, hipad_stream_t stream);
 
+/* bf16 feature rows (ours; no reference counterpart: the reference widens the fp16 pyramid to fp32 before the op,
+ * models/sparse_detector.py:84-89).  Same contracts as hipad_daf_forward / hipad_daf_backward with `feat_bf16`
+ * [batch_size][num_feat][256] bfloat16 -- the image encoder's own output dtype, so the values are the same and the
+ * results are bit-identical to the fp32 entries on the widened tensor, at half the gather bytes.  grad_feat stays fp32.
+ * Only the 256-channel kernels (num_embeds == 256, num_groups == 8 for the backward, sorted feature gradient);
+ * anything else returns HIPAD_EINVAL. */
+int hipad_daf_forward_bf16(float *out, const void *feat_bf16, const int32_t *spatial_shape,
+                           const int32_t *scale_start_index, const float *loc, const float *weights,
+                           int batch_size, int num_cams, int num_feat, int num_embeds, int num_scale,
+                           int num_anchors, int num_pts, int num_groups, void *workspace, size_t workspace_bytes,
+                           hipad_stream_t stream);
+int hipad_daf_backward_bf16(const void *feat_bf16, const int32_t *spatial_shape,
+                            const int32_t *scale_start_index, const float *loc, const float *weights,
+                            const float *grad_out, float *grad_feat, float *grad_loc, float *grad_w,
+                            int batch_size, int num_cams, int num_feat, int num_embeds, int num_scale,
+                            int num_anchors, int num_pts, int num_groups, int flags, void *workspace,
+                            size_t workspace_bytes, hipad_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Index work of the operator, exposed for bit-exact checks (no reference counterpart as a
  * function: it is the integer part of deformable_aggregation_cuda.cu:160-181 + :18-52).

@@ -61,7 +61,7 @@ class EgoInstanceBank(PersistentState, nn.Module):
         if self.with_instance_feat:
             feature = self.instance_feature[None].expand(batch_size, -1, -1).contiguous()
         else:
-            front = feature_maps_format(feature_maps, inverse=True)[0][-1][:, 0]  # coarsest level, front camera
+            front = feature_maps_format(feature_maps, inverse=True)[0][-1][:, 0].float()  # coarsest level, front camera
             feature = self.ego_feature_encoder(front).flatten(1)[:, None]
         return feature, self.anchor[None].expand(batch_size, -1, -1).contiguous()
 

@@ -79,6 +79,7 @@ class PlanningInstanceBank(PersistentState, nn.Module):
             feature = self.instance_feature[None].expand(batch_size, -1, -1).contiguous()
         else:
             coarsest = feature_maps_format(feature_maps, inverse=True)[0][-1]  # (bs, cams, C, h, w)
+            coarsest = coarsest[:, :3 if self.with_all_front_views else 1].float()     # the flat pyramid may be bf16
             if self.with_all_front_views:
                 bs, nc, C, h, w = coarsest[:, :3].shape
                 pooled = self.plan_feature_encoder(coarsest[:, :3].reshape(-1, C, h, w)).reshape(bs, nc, C).sum(1)

@@ -22,6 +22,11 @@ from .image_encoder import BatchNorm2d as _EncoderBN
 __all__ = ["SparseDetector"]
 
 
+import os as _os
+
+FLAT_BF16 = _os.environ.get("HIPAD_FLAT_BF16", "1") == "1"   # 0: widen the flat pyramid to fp32 (round-1 behaviour)
+
+
 @DETECTORS.register_module()
 class SparseDetector(BaseModule):
     def __init__(self, img_backbone, head, img_neck=None, init_cfg=None, train_cfg=None, test_cfg=None,
@@ -79,7 +84,10 @@ class SparseDetector(BaseModule):
         depths = None
         if return_depth and self.depth_branch is not None:
             depths = self.depth_branch(levels, None if metas is None else metas.get("focal"))
-        feature_maps = feature_maps_format(levels, out_dtype=torch.float32)
+        # the flat pyramid keeps the encoder's dtype: bf16 rows go to the aggregation kernels as they are (same values as
+        # the reference's fp32 copy of its fp16 pyramid would hold, half the bytes); other widths / dtypes are widened
+        keep = levels[0].dtype == torch.bfloat16 and levels[0].is_cuda and levels[0].shape[2] == 256 and FLAT_BF16
+        feature_maps = feature_maps_format(levels, out_dtype=None if keep else torch.float32)
         feature_maps[0] = shared_feature_grad(feature_maps[0])
         # cut point of the eager step's two-part backward (hipad_amd.frame.TrainStep); rides on the flat tensor so that it
         # lives exactly as long as the forward's outputs (a persistent reference on the module kills ROCm 7.2's

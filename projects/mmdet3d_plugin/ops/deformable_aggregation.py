@@ -61,6 +61,15 @@ def _as_f32(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _feat_rows(t, weights):
+    """The feature tensor as the kernels take it: the encoder's bf16 rows as they are when the 256-channel kernels apply
+    (hipad_daf_forward_bf16 / _backward_bf16: same values, half the gather bytes), else contiguous fp32."""
+    if (t.dtype == torch.bfloat16 and t.is_cuda and t.is_contiguous() and t.shape[-1] == 256 and weights.shape[-1] == 8
+            and not _ATOMIC_FEAT and not _CROSS_CHECK):
+        return t
+    return _as_f32(t)
+
+
 class _FeatureGradSink(Function):
     """Identity on the feature tensor; collects d(loss)/d(feat) of all consumers in one buffer."""
 
@@ -104,7 +113,7 @@ class DeformableAggregationFunction(Function):
     @staticmethod
     def forward(ctx, mc_ms_feat, spatial_shape, scale_start_index, sampling_location, weights, token=None):
         holder = getattr(mc_ms_feat, "_hipad_grad_holder", None)
-        feat = _as_f32(mc_ms_feat)
+        feat = _feat_rows(mc_ms_feat, weights)
         ss = _as_i32(spatial_shape)
         st = _as_i32(scale_start_index)
         loc = _as_f32(sampling_location)
@@ -131,12 +140,12 @@ class DeformableAggregationFunction(Function):
             key = torch.cuda.current_stream(feat.device).cuda_stream
             grad_feat = ctx.holder["bufs"].get(key)
             if grad_feat is None:
-                grad_feat = ctx.holder["bufs"][key] = torch.zeros_like(feat)
+                grad_feat = ctx.holder["bufs"][key] = torch.zeros(feat.shape, dtype=torch.float32, device=feat.device)
             grad_token = ctx.holder.get("zero")
             if grad_token is None:
                 grad_token = torch.zeros((), dtype=feat.dtype, device=feat.device)
         elif need_feat:
-            grad_feat = ret_feat = torch.zeros_like(feat)
+            grad_feat = ret_feat = torch.zeros(feat.shape, dtype=torch.float32, device=feat.device)
         if _CROSS_CHECK and grad_feat is not None:
             _cross_check(feat, ss, st, loc, w, grad_output)
         _lib.daf_backward(feat, ss, st, loc, w, grad_output, grad_feat, grad_loc, grad_w, overwrite_loc_w=True,

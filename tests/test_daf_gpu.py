@@ -235,3 +235,48 @@ def test_bad_dims_return_error(lib):
     L = lib.load()
     assert L.hipad_daf_forward(None, None, None, None, None, None, 1, 6, 100, 256, 4, 10, 13, 8, None, 0, None) == -1
     assert L.hipad_daf_forward(None, None, None, None, None, None, 1, 6, 100, 250, 4, 10, 13, 8, None, 0, None) == -1
+
+
+@pytest.mark.parametrize("kind", ["det", "map", "plan"])
+def test_bf16_feature_rows_are_bit_identical_to_the_widened_tensor(lib, kind):
+    """hipad_daf_forward_bf16 / _backward_bf16 read the encoder's bf16 rows directly; on a pyramid whose values are bf16
+    the results (output, grad_loc, grad_w, grad_feat) equal the fp32 entries on the widened tensor bit for bit -- the
+    arithmetic is the same, only the load is half as wide.  Shapes of the stage-2 calls, bs 2 for one of them; through
+    the op's autograd surface as well (grad of a bf16 feature tensor comes back as bf16)."""
+    from projects.mmdet3d_plugin.ops import deformable_aggregation_function as DAF
+    torch.manual_seed(7)
+    shapes = [(64, 176), (32, 88), (16, 44), (8, 22)]
+    cams, C, G = 6, 256, 8
+    bs, A, P = {"det": (2, 900, 13), "map": (1, 100, 300), "plan": (1, 480, 90)}[kind]
+    ss = torch.tensor([shapes] * cams, dtype=torch.int32, device="cuda")
+    sizes = (ss[..., 0] * ss[..., 1]).reshape(-1)
+    st = (sizes.cumsum(0) - sizes).reshape(cams, len(shapes)).int()
+    F_ = int(sizes.sum())
+    feat16 = torch.randn(bs, F_, C, device="cuda").to(torch.bfloat16)
+    feat32 = feat16.float()
+    loc = torch.rand(bs, A, P, cams, 2, device="cuda") * 1.6 - 0.3
+    w = torch.softmax(torch.randn(bs, A, P * cams * len(shapes), G, device="cuda"), 2).reshape(bs, A, P, cams, len(shapes), G).contiguous()
+    gout = torch.randn(bs, A, C, device="cuda")
+    o32 = lib.daf_forward(feat32, ss, st, loc, w)
+    o16 = lib.daf_forward(feat16, ss, st, loc, w)
+    assert torch.equal(o32, o16)
+    res = {}
+    for name, f in (("f32", feat32), ("bf16", feat16)):
+        gf = torch.zeros(bs, F_, C, device="cuda")
+        gl, gw = torch.full_like(loc, float("nan")), torch.full_like(w, float("nan"))
+        lib.daf_backward(f, ss, st, loc, w, gout, gf, gl, gw, overwrite_loc_w=True)
+        res[name] = (gf, gl, gw)
+    for a, b in zip(res["f32"], res["bf16"]):
+        assert torch.equal(a, b)
+    # autograd surface
+    f = feat16.clone().requires_grad_(True)
+    l2, w2 = loc.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    out = DAF(f, ss.long(), st.long(), l2, w2)
+    assert torch.equal(out, o32)
+    out.backward(gout)
+    assert f.grad.dtype == torch.bfloat16 and torch.equal(f.grad, res["f32"][0].to(torch.bfloat16))
+    assert torch.equal(l2.grad, res["f32"][1]) and torch.equal(w2.grad, res["f32"][2])
+    # widths the 256-channel kernels do not cover are refused by the bf16 entries (the wrapper widens instead)
+    from hipad_amd.lib import HipadError
+    with pytest.raises(HipadError):
+        lib.daf_forward(feat16[..., :128].contiguous(), ss, st, loc, w[..., :4].contiguous())
