@@ -16,7 +16,7 @@ Workloads
                all-reduce (RCCL) -> clip -> AdamW.  --plan-queries 48 gives BASELINE.json's 6x8 wording.
   daf_stage2   the aggregation path of one stage-2 frame: for each of the 6 decoder layers the
                four deformable-aggregation calls (det 900x13, map 100x300, plan 480x90, ego 1x13
-               key points; 6 cams x 4 levels x 8 groups; C=256 fp32) forward AND backward on the
+               key points; 6 cams x 4 levels x 8 groups; C=256, bf16 pyramid rows, fp32 arithmetic) forward AND backward on the
                89 760-position pyramid.  This is the hand-written-kernel part of the frame; the
                rest of the model is not in this number (config.workload says so).
 Inputs are resident in HBM before the timed region.  `roofline` is for the dominant kernel, timed
@@ -82,8 +82,9 @@ class DafStage2:
         self.F = F
         self.ss = torch.from_numpy(ss).to(device)
         self.st = torch.from_numpy(st).to(device)
-        self.feat = torch.randn(1, F, 256, generator=g).to(device)
-        self.gfeat = torch.zeros_like(self.feat)
+        # bf16 rows, as the training step hands them over (the encoder's output dtype; hipad_daf_*_bf16); grad_feat is fp32
+        self.feat = torch.randn(1, F, 256, generator=g).to(device).to(torch.bfloat16)
+        self.gfeat = torch.zeros(1, F, 256, dtype=torch.float32, device=device)
         pm, wh = syn.projection_mats(hw)
         names = ["det", "map", "plan" if plan_queries == 480 else "plan48", "ego"]
         self.calls = []
@@ -107,7 +108,7 @@ class DafStage2:
 
     def unique_rows(self, loc):
         """Distinct pyramid rows the in-bounds bilinear corners of ``loc`` touch (the kernels' own index work,
-        hipad_daf_taps): the compulsory pyramid traffic of a call is rows x 1 KiB."""
+        hipad_daf_taps): the compulsory pyramid traffic of a call is rows x 512 B (bf16 rows)."""
         valid, taps = self.lib.daf_taps(self.ss, self.st, loc, self.F)
         L = self.ss.shape[1]
         h_low, w_low, mask, base = taps[..., 0].long(), taps[..., 1].long(), taps[..., 2], taps[..., 3].long()
@@ -128,12 +129,12 @@ class DafStage2:
         wbytes = 4 * A * P * 6 * 4 * 8
         lbytes = 4 * A * P * 6 * 2
         obytes = 4 * A * 256
-        fbytes = 4 * 256 * d["rows_touched"]       # compulsory pyramid traffic: every touched row once
+        fbytes = 2 * 256 * d["rows_touched"]       # compulsory pyramid traffic: every touched bf16 row (512 B) once
         if kind == "fwd":
             return wbytes + lbytes + obytes + fbytes
         if kind == "bwd_lw":   # reads w, loc, grad_out, feat; writes grad_w, grad_loc
             return (wbytes + lbytes + obytes + fbytes) + (wbytes + lbytes)
-        return wbytes + lbytes + obytes + 2 * fbytes  # bwd_feat: read-modify-write of grad_feat
+        return wbytes + lbytes + obytes + 2 * (4 * 256 * d["rows_touched"])  # bwd_feat: read-modify-write of fp32 grad_feat rows
 
     def fwd(self, d):
         self.lib.daf_forward(self.feat, self.ss, self.st, d["loc"], d["w"], out=d["out"])
@@ -178,7 +179,7 @@ class DafStage2:
         """CPU oracle (scalar C restatement of the CUDA kernels, 1 core): forward+backward of the four
         calls of ONE decoder layer, repeated until `seconds` have passed; a frame is 6 such layers."""
         from oracle import daf as O
-        feat = self.feat.cpu().numpy()
+        feat = self.feat.float().cpu().numpy()
         ss, st = self.ss.cpu().numpy(), self.st.cpu().numpy()
         spent, reps = 0.0, 0
         while spent < seconds:
@@ -455,7 +456,7 @@ def main():
                     "assignment [det/map/motion/ego/plan/depth terms] + backward + grad all-reduce + clip + AdamW) of "
                     f"hipad_b2d_stage{wl.stage} on one 6-cam {hw_txt} frame per GPU: {enc_txt}, decoder det 900 "
                     f"+ map 100 + plan {a.plan_queries} + ego 1 queries x 6 layers + motion head, bf16 GEMMs / bf16-operand "
-                    "attention, fp32 aggregation; synthetic ground truth (~20 boxes, ~10 map lines per frame)")
+                    "attention, fp32 aggregation arithmetic on the encoder's bf16 pyramid rows; synthetic ground truth (~20 boxes, ~10 map lines per frame)")
         dtype = "f32" if a.workload == "stage1_fp32" else "bf16"
         cfg = dict(workload=workload, frames_per_gpu_per_step=a.bs, plan_queries=a.plan_queries, parallelism=f"dp{world}",
                    launch="eager (decoder-segment all-reduce overlapped with the encoder's backward)" if a.eager else

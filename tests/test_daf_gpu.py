@@ -266,15 +266,18 @@ def test_bf16_feature_rows_are_bit_identical_to_the_widened_tensor(lib, kind):
         gl, gw = torch.full_like(loc, float("nan")), torch.full_like(w, float("nan"))
         lib.daf_backward(f, ss, st, loc, w, gout, gf, gl, gw, overwrite_loc_w=True)
         res[name] = (gf, gl, gw)
-    for a, b in zip(res["f32"], res["bf16"]):
-        assert torch.equal(a, b)
+    # grad_loc / grad_w: bit for bit.  grad_feat: rows that straddle two tap batches are finished with fp32 atomics, whose
+    # order differs from launch to launch (two launches on the SAME input differ as much): equal to rounding
+    assert torch.equal(res["f32"][1], res["bf16"][1]) and torch.equal(res["f32"][2], res["bf16"][2])
+    assert float((res["f32"][0] - res["bf16"][0]).abs().max() / res["f32"][0].abs().max()) < 1e-6
     # autograd surface
     f = feat16.clone().requires_grad_(True)
     l2, w2 = loc.clone().requires_grad_(True), w.clone().requires_grad_(True)
     out = DAF(f, ss.long(), st.long(), l2, w2)
     assert torch.equal(out, o32)
     out.backward(gout)
-    assert f.grad.dtype == torch.bfloat16 and torch.equal(f.grad, res["f32"][0].to(torch.bfloat16))
+    assert f.grad.dtype == torch.bfloat16
+    assert float((f.grad.float() - res["f32"][0]).abs().max() / res["f32"][0].abs().max()) < 5e-3      # one bf16 rounding
     assert torch.equal(l2.grad, res["f32"][1]) and torch.equal(w2.grad, res["f32"][2])
     # widths the 256-channel kernels do not cover are refused by the bf16 entries (the wrapper widens instead)
     from hipad_amd.lib import HipadError
