@@ -328,7 +328,7 @@ def _daf_grid_threads(A, P, cams=6, bs=1):
     return ((n_anchor * nchunks + 3) // 4) * 256
 
 
-PMC_FILE = "r01k_daf_pmc_traffic.json"
+PMC_FILE = "r02y_daf_pmc_traffic.json"
 
 
 def pmc_traffic(kernel, A, P):
@@ -339,7 +339,12 @@ def pmc_traffic(kernel, A, P):
         return None
     with open(path) as f:
         table = json.load(f)["kernels"]
-    hit = table.get("hipad::%s grid=%d" % (kernel, _daf_grid_threads(A, P)))
+    if kernel == "daf_bwd_feat_kernel":
+        # persistent grid (2048 x 256 threads) for every large call: the counters cannot tell the det / map / plan
+        # launches apart -- the figure is their average (traffic_source says so)
+        hit = table.get("hipad::daf_bwd_feat_kernel grid=524288")
+    else:
+        hit = table.get("hipad::%s grid=%d" % (kernel, _daf_grid_threads(A, P)))
     return None if hit is None else hit["hbm_bytes_per_launch"]
 
 
@@ -361,13 +366,15 @@ def roofline_of(daf, layers=6):
     achieved = alg / (kt[dom] * 1e-3) / 1e9
     kname = {"fwd": "daf_fwd_c256_kernel<4, true> (+ combine)", "bwd_lw": "daf_bwd_lw_kernel<4, true, true>",
              "bwd_feat": "feature-gradient pipeline (daf_tap_pass x2, daf_alloc, daf_bwd_feat_kernel)"}[dom[1]]
-    pmc_name = {"fwd": "daf_fwd_c256_kernel<4, true>", "bwd_lw": "daf_bwd_lw_kernel<4, true, true>",
-                "bwd_feat": "daf_bwd_feat_kernel"}[dom[1]]
+    pmc_name = {"fwd": "daf_fwd_c256_kernel<4, true, unsigned short>",
+                "bwd_lw": "daf_bwd_lw_kernel<4, true, true, unsigned short>", "bwd_feat": "daf_bwd_feat_kernel"}[dom[1]]
     return dict(bound="hbm", kernel=f"{kname} [{dom[0]}: A={dcall['A']} P={dcall['P']}]",
                 achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                 traffic=pmc_traffic(pmc_name, dcall["A"], dcall["P"]),
                 traffic_source="profiles/" + PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                               "`bench.py --workload daf_stage2`, bytes per launch)",
+                               "`bench.py --workload daf_stage2`, bytes per launch" +
+                               ("; daf_bwd_feat_kernel only -- the payload kernel of the pipeline -- averaged over the det / map / "
+                                "plan launches, which share one persistent grid)" if dom[1] == "bwd_feat" else ")"),
                 alg_bytes_per_launch=alg, avg_launch_ms=round(kt[dom], 4),
                 rows_touched=dcall["rows_touched"], kept_pairs=dcall["kept_pairs"],
                 aggregation_launches=table)
