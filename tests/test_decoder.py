@@ -106,7 +106,11 @@ def test_decoder_two_frames_match_reference(golden, mode):
     # heads sit at 8-10e-2 in the max norm and move by a few e-2 with ANY 1e-6 change of arithmetic (observed when the
     # LayerNorm after a Linear moved into that Linear's kernel: bit-identical activations, 1e-6 in the normalised
     # output) -- bounded at 0.13 there.
-    TOL = TOL_DEEP = 1e-2 if mode == "torch_fp32" else 8e-2
+    # Round 2: the chain kernels keep the activations as hi + lo bf16 pairs (only the weights are rounded), which took the
+    # frame-0 worst element from 8e-2 to 3.8e-2 -- bound 5e-2.  This whole-decoder comparison measures how a random-init
+    # network AMPLIFIES operand rounding; the per-operator 1e-2 pins of the bf16 configuration are the teacher-forced
+    # tests below (test_bf16_configuration_is_pinned_op_by_op, ..._loss_terms_track_fp32).
+    TOL = TOL_DEEP = 1e-2 if mode == "torch_fp32" else 5e-2
     # frame 1, last layer, bf16 operands: the worst element over 900 instances is heavy-tailed (a reordered fp32 sum in
     # LayerNorm moves it between 0.09 and 0.23 -- one instance whose temporal top-k neighbour changed), so that case is
     # bounded by the 99th percentile of the element errors plus a loose cap on the worst one
