@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="launch the step kernel by kernel instead of replaying hipGraphs")
     ap.add_argument("--bs", type=int, default=1, help="frames per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--comm-dtype", default="fp32", choices=("fp32", "bf16"),
+                    help="wire dtype of the gradient all-reduce at N > 1 (fp32 = the reference's DDP behaviour)")
     return ap.parse_args()
 
 
@@ -199,7 +201,7 @@ class DafStage2:
 class Stage2Full:
     """One training step of the whole model per frame (see module docstring)."""
 
-    def __init__(self, device, seed, plan_queries=480, bs=1, eager=False, hw=(256, 704), stage=2, **build):
+    def __init__(self, device, seed, plan_queries=480, bs=1, eager=False, hw=(256, 704), stage=2, comm_dtype=None, **build):
         import warnings
         warnings.filterwarnings("ignore", category=DeprecationWarning)
         from hipad_amd.frame import GraphedTrainStep, SyntheticFrames, TrainStep, build_detector
@@ -210,10 +212,10 @@ class Stage2Full:
         self.hw, self.stage = hw, stage
         self.bs, self.plan_queries, self.eager = bs, plan_queries, eager
         if eager:
-            self.train_step = TrainStep(self.model, self.cfg)
+            self.train_step = TrainStep(self.model, self.cfg, comm_dtype=comm_dtype)
             self.graphed = None
         else:
-            self.graphed = GraphedTrainStep(self.model, self.cfg, self.frames)  # warms up (cold frames) + captures
+            self.graphed = GraphedTrainStep(self.model, self.cfg, self.frames, comm_dtype=comm_dtype)  # warm-up + capture
             self.train_step = self.graphed.inner
         self.daf = DafStage2(device, seed, plan_queries, hw=hw)  # op-level harness for the roofline / cpu legs
 
@@ -420,7 +422,8 @@ def main():
         extra = dict(hw=(640, 1600), backbone_depth=101)
     elif a.workload == "stage1_fp32":      # BASELINE.json config 2
         extra = dict(stage=1, encoder_dtype=torch.float32)
-    wl = (Stage2Full(dev, seed=rank, plan_queries=a.plan_queries, bs=a.bs, eager=a.eager, **extra) if full
+    comm = torch.bfloat16 if (a.comm_dtype == "bf16" and world > 1) else None
+    wl = (Stage2Full(dev, seed=rank, plan_queries=a.plan_queries, bs=a.bs, eager=a.eager, comm_dtype=comm, **extra) if full
           else Stage2Infer(dev, seed=rank, plan_queries=a.plan_queries) if infer
           else DafStage2(dev, seed=rank, plan_queries=a.plan_queries))
 
@@ -466,6 +469,7 @@ def main():
                     "attention, fp32 aggregation arithmetic on the encoder's bf16 pyramid rows; synthetic ground truth (~20 boxes, ~10 map lines per frame)")
         dtype = "f32" if a.workload == "stage1_fp32" else "bf16"
         cfg = dict(workload=workload, frames_per_gpu_per_step=a.bs, plan_queries=a.plan_queries, parallelism=f"dp{world}",
+                   grad_allreduce_dtype=("none (1 rank)" if world == 1 else a.comm_dtype),
                    launch="eager (decoder-segment all-reduce overlapped with the encoder's backward)" if a.eager else
                    ("hipGraph replay: forward+losses+backward graph, clip+AdamW graph" if world == 1 else
                     "hipGraph replay: forward graph | positive-count all-reduce | losses+backward graph | flat-gradient "
