@@ -424,6 +424,11 @@ def _tile(t, layers):
     return t.repeat((layers,) + (1,) * (t.dim() - 1))
 
 
+import os as _os
+
+PLAN_LOSS_BATCHED = _os.environ.get("HIPAD_PLAN_LOSS_BATCHED", "1") == "1"   # 0: the group-by-group form
+
+
 class DecoderLoss:
     """``loss()`` of SparseOneDecoder (mixed into the class in sparse_onedecoder.py).
 
@@ -567,6 +572,100 @@ class DecoderLoss:
         return cls_loss.reshape(layers), reg_loss.reshape(layers)
 
     def loss_plan(self, outs, data):
+        single_cmd = all(getattr(smp, "ego_fut_cmd", 1) == 1 for smp in (self.plan_sampler, self.align_sampler)) \
+            and self.ego_fut_cmd == 1
+        known = all(t[0] in ("temp", "spat", "speed") for t in self.plan_anchor_types)
+        if single_cmd and known and PLAN_LOSS_BATCHED:
+            return self._loss_plan_batched(outs, data)
+        return self._loss_plan_general(outs, data)
+
+    def _loss_plan_batched(self, outs, data):
+        """The planning terms with ALL anchor groups evaluated together (single driving command, as the stage configs
+        have it): the reference walks the ten anchor types one by one (sparse_onedecoder.py:1315-1443) -- ten target
+        selections, six classification and six regression losses, each a dozen small launches forward and again backward.
+        Here the groups are a tensor dimension: one gather of the reference mode's trajectory / logit for every group,
+        ONE focal loss over the aligned groups, ONE over the speed buckets, ONE L1 over all trajectories, with the
+        (group, layer) pairs stacked where the loss modules expect the layers, so every term is still reduced per
+        group and per layer exactly as in the group-by-group form (_loss_plan_general; tests/test_losses.py compares)."""
+        layers = len(outs["classification"])
+        cls, reg = _stack_layers(outs["classification"]), _stack_layers(outs["prediction"])
+        data = {k: (_tile(v, layers) if k.startswith("gt_ego_") else v) for k, v in data.items()}
+        types = list(self.plan_anchor_types)
+        G = self.plan_anchor_group
+        B, ts = cls.shape[0], reg.shape[-2]
+        modes = reg.size(2) // G
+        cls_g, reg_g = cls.reshape(B, G, modes), reg.reshape(B, G, modes, ts, 2)
+        r = types.index(self.plan_anchor_refer)
+        ref_gt, ref_mask = self._plan_gt(data, self.plan_anchor_refer)
+        # the winning mode of the reference group decides the target mode of every other group
+        _, ref_target, ref_weight, _, _, _ = self.plan_sampler.sample(cls_g[:, r:r + 1], reg_g[:, r:r + 1], ref_gt, ref_mask, data)
+        best = torch.gather(reg_g, 2, ref_target[:, :, None, None, None].expand(B, G, 1, ts, 2)).squeeze(2)   # (B, G, ts, 2)
+        logit = torch.gather(cls_g, 2, ref_target[:, :, None].expand(B, G, 1)).squeeze(2)                       # (B, G)
+
+        def group_major(t):       # (B, n, ...) -> (n * B, ...): rows ordered (group, layer, sample)
+            return t.transpose(0, 1).reshape((-1,) + tuple(t.shape[2:]))
+
+        align = [i for i, t in enumerate(types) if t[0] in ("temp", "spat")]
+        n_a = len(align)
+        a_idx = _const(align, logit).long() if align != list(range(align[0], align[0] + n_a)) else None
+        take = (lambda t: t.index_select(1, a_idx)) if a_idx is not None else (lambda t: t[:, align[0]:align[0] + n_a])
+        gts = [self._plan_gt(data, types[i]) for i in align]
+        a_gt, a_mask = torch.stack([g for g, _ in gts], 1), torch.stack([m for _, m in gts], 1)      # (B, n_a, ts, 2), (B, n_a, ts)
+        a_cls = self.loss_plan_cls(group_major(take(cls_g)), ref_target.flatten().repeat(n_a),
+                                   weight=ref_weight.flatten().repeat(n_a), layers=n_a * layers).reshape(n_a, layers)
+        # speed groups: per interval the buckets' logits / trajectories of the reference mode; class = the speed bucket
+        intervals = {}
+        for i, t in enumerate(types):
+            if t[0] == "speed":
+                intervals.setdefault(t[1], []).append(i)
+        sp_traj, sp_mask = self._plan_gt(data, self.plan_speed_refer)
+        interval = 1 / float(self.plan_speed_refer[1].split("hz")[0])
+        speed = torch.linalg.norm(sp_traj, dim=-1).sum(-1) / (sp_mask.sum(-1) * interval + 1e-4)              # (B,)
+        sp_any = sp_mask.any(dim=-1)
+        s_logits, s_best, s_gt, s_mask, s_bucket = [], [], [], [], []
+        for name, idx in intervals.items():
+            areas = [types[i][2] for i in idx]
+            bucket = torch.ones_like(speed, dtype=torch.long)
+            for k, (lo, hi) in enumerate(areas):
+                bucket = torch.where((speed >= lo) & (speed < hi), torch.full_like(bucket, k), bucket)
+            contiguous = idx == list(range(idx[0], idx[0] + len(idx)))
+            sel = (lambda t, idx=idx: t[:, idx[0]:idx[0] + len(idx)]) if contiguous else \
+                (lambda t, idx=idx: t.index_select(1, _const(idx, logit).long()))
+            s_logits.append(sel(logit))                                                                          # (B, K)
+            s_best.append(torch.gather(sel(best), 1, bucket[:, None, None, None].expand(B, 1, ts, 2)).squeeze(1))  # (B, ts, 2)
+            g_traj, g_mask = self._plan_gt(data, types[idx[0]])
+            s_gt.append(g_traj); s_mask.append(g_mask); s_bucket.append(bucket)
+        n_s = len(intervals)
+        if n_s and len({t.shape[1] for t in s_logits}) != 1:
+            return self._loss_plan_general(outs, data)        # intervals with different numbers of buckets
+        if n_s:
+            s_cls = self.loss_plan_cls(torch.cat(s_logits, 0), torch.cat(s_bucket, 0), weight=sp_any.repeat(n_s),
+                                       layers=n_s * layers).reshape(n_s, layers)
+        # one L1 over the trajectories of the aligned groups and of the speed intervals
+        pred = [group_major(take(best))] + s_best
+        tgt = [group_major(a_gt)] + s_gt
+        msk = [group_major(a_mask)] + s_mask
+        n_all = n_a + n_s
+        all_reg = self.loss_plan_reg(torch.cat(pred, 0).cumsum(dim=-2), torch.cat(tgt, 0).cumsum(dim=-2),
+                                     weight=torch.cat(msk, 0).unsqueeze(-1), layers=n_all * layers).reshape(n_all, layers)
+        total = {}
+        for j, i in enumerate(align):
+            c, rg = total.setdefault(types[i][0], [0.0, 0.0])
+            total[types[i][0]] = [c + a_cls[j], rg + all_reg[j]]
+        for j in range(n_s):
+            c, rg = total.setdefault("speed", [0.0, 0.0])
+            total["speed"] = [c + s_cls[j], rg + all_reg[n_a + j]]
+        kinds = []
+        for t in types:
+            if t[0] not in kinds:
+                kinds.append(t[0])
+        output = {}
+        for k in kinds:
+            self._add(output, f"plan_loss_{k}_cls", total[k][0])
+            self._add(output, f"plan_loss_{k}_reg", total[k][1])
+        return output
+
+    def _loss_plan_general(self, outs, data):
         layers = len(outs["classification"])
         cls, reg = _stack_layers(outs["classification"]), _stack_layers(outs["prediction"])
         data = {k: (_tile(v, layers) if k.startswith("gt_ego_") else v) for k, v in data.items()}
