@@ -618,11 +618,12 @@ class DecoderLoss:
         for i, t in enumerate(types):
             if t[0] == "speed":
                 intervals.setdefault(t[1], []).append(i)
-        sp_traj, sp_mask = self._plan_gt(data, self.plan_speed_refer)
-        interval = 1 / float(self.plan_speed_refer[1].split("hz")[0])
-        speed = torch.linalg.norm(sp_traj, dim=-1).sum(-1) / (sp_mask.sum(-1) * interval + 1e-4)              # (B,)
-        sp_any = sp_mask.any(dim=-1)
         s_logits, s_best, s_gt, s_mask, s_bucket = [], [], [], [], []
+        if intervals:       # (stage 1 has a single temporal group and no speed groups)
+            sp_traj, sp_mask = self._plan_gt(data, self.plan_speed_refer)
+            interval = 1 / float(self.plan_speed_refer[1].split("hz")[0])
+            speed = torch.linalg.norm(sp_traj, dim=-1).sum(-1) / (sp_mask.sum(-1) * interval + 1e-4)          # (B,)
+            sp_any = sp_mask.any(dim=-1)
         for name, idx in intervals.items():
             areas = [types[i][2] for i in idx]
             bucket = torch.ones_like(speed, dtype=torch.long)
