@@ -1,4 +1,4 @@
-from .augment import ResizeCropFlipImage
+from .augment import BBoxRotation, ResizeCropFlipImage
 from .transform import DeviceImageTransform, NormalizeMultiviewImage
 
-__all__ = ["ResizeCropFlipImage", "NormalizeMultiviewImage", "DeviceImageTransform"]
+__all__ = ["ResizeCropFlipImage", "BBoxRotation", "NormalizeMultiviewImage", "DeviceImageTransform"]

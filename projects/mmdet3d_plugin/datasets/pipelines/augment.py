@@ -10,7 +10,7 @@ import torch
 from hipad_amd import imgpipe
 from hipad_amd.compat import PIPELINES
 
-__all__ = ["ResizeCropFlipImage"]
+__all__ = ["ResizeCropFlipImage", "BBoxRotation"]
 
 
 def _stack(imgs):
@@ -45,3 +45,32 @@ class ResizeCropFlipImage(object):
         results["img"] = list(out.unbind(0))
         results["img_shape"] = [tuple(x.shape[:2]) for x in results["img"]]
         return results
+
+
+@PIPELINES.register_module()
+class BBoxRotation(object):
+    """Rotation of the scene about the vertical axis by ``aug_config["rotate_3d"]`` (reference
+    datasets/pipelines/augment.py:95-138): the lidar -> image and lidar -> global matrices absorb the inverse rotation,
+    box centres / yaws / velocities turn with the scene.  Host logic on 4x4 matrices and a handful of boxes (numpy)."""
+
+    def __call__(self, results):
+        angle = results["aug_config"]["rotate_3d"]
+        c, s_ = np.cos(angle), np.sin(angle)
+        undo = np.linalg.inv(np.array([[c, -s_, 0, 0], [s_, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]]))
+        results["lidar2img"] = [m @ undo for m in results["lidar2img"]]
+        if "lidar2global" in results:
+            results["lidar2global"] = results["lidar2global"] @ undo
+        if "gt_bboxes_3d" in results:
+            results["gt_bboxes_3d"] = self.box_rotate(results["gt_bboxes_3d"], angle)
+        return results
+
+    @staticmethod
+    def box_rotate(bbox_3d, angle):
+        c, s_ = np.cos(angle), np.sin(angle)
+        turn = np.array([[c, s_, 0], [-s_, c, 0], [0, 0, 1]])           # row vectors: p' = p @ turn
+        bbox_3d[:, :3] = bbox_3d[:, :3] @ turn
+        bbox_3d[:, 6] += angle
+        if bbox_3d.shape[-1] > 7:
+            n = bbox_3d[:, 7:].shape[-1]
+            bbox_3d[:, 7:] = bbox_3d[:, 7:] @ turn[:n, :n]
+        return bbox_3d

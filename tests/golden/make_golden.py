@@ -533,6 +533,16 @@ def gen_pipeline():
         out[f"img_{k}"] = np.stack(res["img"]).astype(np.uint8)        # float32 holding integers 0..255: stored as bytes
         assert np.array_equal(out[f"img_{k}"].astype(np.float32), np.stack(res["img"]))
         out[f"lidar2img_{k}"] = np.stack(res["lidar2img"])
+    # ---- BBoxRotation (augment.py:95-138): matrices and boxes of one sample ----
+    rot = aug_mod.BBoxRotation()
+    boxes = rng.normal(size=(7, 9))
+    l2g = rng.normal(size=(4, 4))
+    out["rot3d_boxes"], out["rot3d_lidar2global"] = boxes, l2g
+    for k, ang in enumerate((0.3, -1.1, 0.0)):
+        res = rot(dict(aug_config=dict(rotate_3d=ang), lidar2img=[m.copy() for m in l2i], lidar2global=l2g.copy(),
+                       gt_bboxes_3d=boxes.copy()))
+        out[f"rot3d_{k}_lidar2img"] = np.stack(res["lidar2img"])
+        out[f"rot3d_{k}_lidar2global"], out[f"rot3d_{k}_boxes"] = res["lidar2global"], res["gt_bboxes_3d"]
     # ---- sampler: 9 sequences of 3..11 frames, two ranks x batch 2, skipping and reversal on ----
     lens = [5, 3, 7, 4, 11, 6, 3, 8, 5]
     flag = np.concatenate([np.full(n, g) for g, n in enumerate(lens)])

@@ -158,3 +158,14 @@ def test_device_entry_refuses_host_tensors():
     from hipad_amd.lib import HipadError
     with pytest.raises(HipadError):
         P.transform_images(torch.zeros(1, 8, 8, 3, dtype=torch.uint8), dict(resize=1.0))
+
+
+def test_bbox_rotation_equals_reference():
+    from projects.mmdet3d_plugin.datasets.pipelines import BBoxRotation
+    rot = BBoxRotation()
+    for k, ang in enumerate((0.3, -1.1, 0.0)):
+        res = rot(dict(aug_config=dict(rotate_3d=ang), lidar2img=[m.copy() for m in G["lidar2img"]],
+                       lidar2global=G["rot3d_lidar2global"].copy(), gt_bboxes_3d=G["rot3d_boxes"].copy()))
+        assert np.allclose(np.stack(res["lidar2img"]), G[f"rot3d_{k}_lidar2img"], rtol=1e-12, atol=1e-12)
+        assert np.allclose(res["lidar2global"], G[f"rot3d_{k}_lidar2global"], rtol=1e-12, atol=1e-12)
+        assert np.allclose(res["gt_bboxes_3d"], G[f"rot3d_{k}_boxes"], rtol=1e-12, atol=1e-12)
