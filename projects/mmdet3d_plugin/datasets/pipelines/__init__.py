@@ -1,4 +1,4 @@
 from .augment import BBoxRotation, ResizeCropFlipImage
-from .transform import DeviceImageTransform, NormalizeMultiviewImage
+from .transform import DeviceImageTransform, NormalizeMultiviewImage, NuScenesSparse4DAdaptor
 
-__all__ = ["ResizeCropFlipImage", "BBoxRotation", "NormalizeMultiviewImage", "DeviceImageTransform"]
+__all__ = ["ResizeCropFlipImage", "BBoxRotation", "NormalizeMultiviewImage", "DeviceImageTransform", "NuScenesSparse4DAdaptor"]

@@ -8,7 +8,7 @@ import torch
 from hipad_amd import imgpipe
 from hipad_amd.compat import PIPELINES
 
-__all__ = ["NormalizeMultiviewImage", "DeviceImageTransform"]
+__all__ = ["NormalizeMultiviewImage", "DeviceImageTransform", "NuScenesSparse4DAdaptor"]
 
 
 @PIPELINES.register_module()
@@ -67,3 +67,51 @@ class DeviceImageTransform(object):
             results["projection_mat"] = np.float32(np.stack(results["lidar2img"]))
             results["image_wh"] = np.ascontiguousarray(np.array(results["img_shape"], dtype=np.float32)[:, :2][:, ::-1])
         return results
+
+
+def _tensor(x):
+    return x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))
+
+
+@PIPELINES.register_module()
+class NuScenesSparse4DAdaptor(object):
+    """Last pipeline step before ``Collect`` (reference datasets/pipelines/transform.py:107-168): the per-sample
+    projection matrices / image sizes / pose inverses the decoder reads, yaw wrapped into (-pi, pi], ground truth as
+    tensors, images stacked channels-first.  Host logic; the values are plain tensors (mmcv's DataContainer only tells
+    its collate function how to batch them -- hipad_amd.frame batches by stacking / padding itself).  Images that are
+    already a (n, 3, h, w) tensor (DeviceImageTransform) or device (h, w, 3) tensors stay on their device."""
+
+    GT_LIST_KEYS = ("gt_map_labels", "gt_map_pts", "gt_agent_fut_trajs", "gt_agent_fut_masks")
+    GT_STACK_KEYS = ("gt_ego_fut_trajs", "gt_ego_fut_masks", "gt_ego_fut_cmd", "command_near_xy", "ego_status")
+
+    def __call__(self, input_dict):
+        input_dict["projection_mat"] = np.float32(np.stack(input_dict["lidar2img"]))
+        input_dict["image_wh"] = np.ascontiguousarray(np.array(input_dict["img_shape"], dtype=np.float32)[:, :2][:, ::-1])
+        input_dict["T_global_inv"] = np.linalg.inv(input_dict["lidar2global"])
+        input_dict["T_global"] = input_dict["lidar2global"]
+        if "cam_intrinsic" in input_dict:
+            input_dict["cam_intrinsic"] = np.float32(np.stack(input_dict["cam_intrinsic"]))
+            input_dict["focal"] = input_dict["cam_intrinsic"][..., 0, 0]
+        if "instance_inds" in input_dict:
+            input_dict["instance_id"] = input_dict["instance_inds"]
+        if "gt_bboxes_3d" in input_dict:
+            boxes = input_dict["gt_bboxes_3d"]
+            boxes[:, 6] = self.limit_period(boxes[:, 6], offset=0.5, period=2 * np.pi)
+            input_dict["gt_bboxes_3d"] = _tensor(boxes).float()
+        if "gt_labels_3d" in input_dict:
+            input_dict["gt_labels_3d"] = _tensor(input_dict["gt_labels_3d"]).long()
+        img = input_dict["img"]
+        if isinstance(img, torch.Tensor) and img.dim() == 4:
+            input_dict["img"] = img                                           # already (n, 3, h, w)
+        elif isinstance(img[0], torch.Tensor):
+            input_dict["img"] = torch.stack(list(img), 0).permute(0, 3, 1, 2).contiguous()
+        else:
+            input_dict["img"] = _tensor(np.ascontiguousarray(np.stack([im.transpose(2, 0, 1) for im in img], axis=0)))
+        for key in self.GT_LIST_KEYS + self.GT_STACK_KEYS:
+            if key in input_dict:
+                input_dict[key] = _tensor(input_dict[key])
+        return input_dict
+
+    @staticmethod
+    def limit_period(val, offset=0.5, period=np.pi):
+        return val - np.floor(val / period + offset) * period

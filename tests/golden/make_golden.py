@@ -17,7 +17,8 @@ tests/golden/_ref_shim.py (third-party names only are stubbed):
   * SparseBox3DKeyPointsGenerator (models/det/blocks.py:159-224),
     SparsePoint3DKeyPointsGenerator (models/map/blocks.py:137-225)
   * --only pipeline: ResizeCropFlipImage (datasets/pipelines/augment.py:11-94), Bench2DriveDataset.get_augmentation
-    (datasets/bench2drive_dataset.py:709-751), GroupInBatchSampler (datasets/samplers/group_in_batch_sampler.py:48-178)
+    (datasets/bench2drive_dataset.py:709-751), GroupInBatchSampler (datasets/samplers/group_in_batch_sampler.py:48-178),
+    BBoxRotation (augment.py:95-138), NuScenesSparse4DAdaptor (pipelines/transform.py:107-168)
 Only data (inputs, parameters drawn from a seed, outputs) is stored.
 """
 import argparse
@@ -543,6 +544,32 @@ def gen_pipeline():
                        gt_bboxes_3d=boxes.copy()))
         out[f"rot3d_{k}_lidar2img"] = np.stack(res["lidar2img"])
         out[f"rot3d_{k}_lidar2global"], out[f"rot3d_{k}_boxes"] = res["lidar2global"], res["gt_bboxes_3d"]
+    # ---- NuScenesSparse4DAdaptor (transform.py:107-168) on one sample; DataContainer stand-in keeps the payload ----
+    import types as _types
+
+    class DC:  # mmcv.parallel.DataContainer: only the payload matters here
+        def __init__(self, data, **kw):
+            self.data = data
+
+    sys.modules["mmcv.parallel"] = _types.ModuleType("mmcv.parallel")
+    sys.modules["mmcv.parallel"].DataContainer = DC
+    sys.modules["mmdet.datasets.pipelines"].to_tensor = lambda x: x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))
+    tr_mod = S.ref_import("datasets.pipelines.transform")
+    ad_in = dict(lidar2img=[m.copy() for m in l2i], img_shape=[(28, 64, 3)] * 6, lidar2global=l2g.copy() + 3 * np.eye(4),
+                 cam_intrinsic=[np.eye(4) * (k + 1) for k in range(6)], instance_inds=np.arange(7),
+                 gt_bboxes_3d=np.concatenate([boxes[:, :6], np.linspace(-9, 9, 7)[:, None], boxes[:, 7:]], 1),
+                 gt_labels_3d=np.arange(7) % 3, img=[rng.normal(size=(8, 12, 3)).astype(np.float32) for _ in range(2)],
+                 gt_ego_fut_cmd=np.eye(3)[1], ego_status=rng.normal(size=10).astype(np.float32),
+                 gt_map_labels=np.arange(4), gt_map_pts=rng.normal(size=(4, 3, 20, 2)))
+    for k, v in ad_in.items():
+        out[f"adaptor_in_{k}"] = np.stack(v) if isinstance(v, list) else np.asarray(v)
+    ad_out = tr_mod.NuScenesSparse4DAdaptor()({k: (list(v) if isinstance(v, list) else (v.copy() if hasattr(v, "copy") else v))
+                                               for k, v in ad_in.items()})
+    for k in ("projection_mat", "image_wh", "T_global_inv", "T_global", "cam_intrinsic", "focal", "instance_id", "gt_bboxes_3d",
+              "gt_labels_3d", "img", "gt_ego_fut_cmd", "ego_status", "gt_map_labels", "gt_map_pts"):
+        v = ad_out[k]
+        v = v.data if isinstance(v, DC) else v
+        out[f"adaptor_out_{k}"] = v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
     # ---- sampler: 9 sequences of 3..11 frames, two ranks x batch 2, skipping and reversal on ----
     lens = [5, 3, 7, 4, 11, 6, 3, 8, 5]
     flag = np.concatenate([np.full(n, g) for g, n in enumerate(lens)])

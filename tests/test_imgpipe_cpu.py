@@ -169,3 +169,27 @@ def test_bbox_rotation_equals_reference():
         assert np.allclose(np.stack(res["lidar2img"]), G[f"rot3d_{k}_lidar2img"], rtol=1e-12, atol=1e-12)
         assert np.allclose(res["lidar2global"], G[f"rot3d_{k}_lidar2global"], rtol=1e-12, atol=1e-12)
         assert np.allclose(res["gt_bboxes_3d"], G[f"rot3d_{k}_boxes"], rtol=1e-12, atol=1e-12)
+
+
+def test_adaptor_step_equals_reference():
+    """NuScenesSparse4DAdaptor: every entry the reference's adaptor produces from the same sample (the DataContainer
+    payloads), incl. the yaw wrap and the HWC -> CHW stack; already-stacked device-style image tensors pass through."""
+    from projects.mmdet3d_plugin.datasets.pipelines import NuScenesSparse4DAdaptor
+    keys = ("lidar2img", "img_shape", "lidar2global", "cam_intrinsic", "instance_inds", "gt_bboxes_3d", "gt_labels_3d", "img",
+            "gt_ego_fut_cmd", "ego_status", "gt_map_labels", "gt_map_pts")
+    sample = {}
+    for k in keys:
+        v = G[f"adaptor_in_{k}"].copy()
+        sample[k] = list(v) if k in ("lidar2img", "cam_intrinsic", "img") else ([tuple(r) for r in v] if k == "img_shape" else v)
+    out = NuScenesSparse4DAdaptor()(sample)
+    for k in ("projection_mat", "image_wh", "T_global_inv", "T_global", "cam_intrinsic", "focal", "instance_id", "gt_bboxes_3d",
+              "gt_labels_3d", "img", "gt_ego_fut_cmd", "ego_status", "gt_map_labels", "gt_map_pts"):
+        got = out[k].numpy() if isinstance(out[k], torch.Tensor) else np.asarray(out[k])
+        want = G[f"adaptor_out_{k}"]
+        assert got.dtype == want.dtype and got.shape == want.shape, (k, got.dtype, want.dtype, got.shape, want.shape)
+        assert np.array_equal(got, want), k
+    yaw = out["gt_bboxes_3d"][:, 6]
+    assert float(yaw.min()) >= -np.pi - 1e-6 and float(yaw.max()) < np.pi + 1e-6
+    stacked = torch.zeros(6, 3, 4, 5)
+    assert NuScenesSparse4DAdaptor()(dict(lidar2img=list(G["lidar2img"]), img_shape=[(4, 5, 3)] * 6, lidar2global=np.eye(4),
+                                         img=stacked))["img"] is stacked
