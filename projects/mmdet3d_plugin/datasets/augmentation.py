@@ -4,7 +4,7 @@ consumed in the reference's order (resize, bottom crop, horizontal crop, flip, r
 reproduces the reference's aug_config stream."""
 import numpy as np
 
-__all__ = ["get_augmentation"]
+__all__ = ["get_augmentation", "invert_pose", "camera_matrices"]
 
 
 def get_augmentation(data_aug_conf, test_mode=False, rng=None):
@@ -35,3 +35,36 @@ def get_augmentation(data_aug_conf, test_mode=False, rng=None):
         "rotate": rotate,
         "rotate_3d": rotate_3d,
     }
+
+
+def invert_pose(pose):
+    """Inverse of a rigid 4x4 pose by transposing the rotation (reference bench2drive_dataset.py:298-302)."""
+    inv = np.eye(4)
+    inv[:3, :3] = pose[:3, :3].T
+    inv[:3, -1] = -inv[:3, :3] @ pose[:3, -1]
+    return inv
+
+
+def camera_matrices(info, data_root=""):
+    """The per-camera matrices of one annotation record (reference bench2drive_dataset.py:763-805,
+    Bench2DriveDataset.get_data_info): for every ``CAM*`` sensor, in record order,
+    ``lidar2img = K_pad @ inv(cam2ego) @ lidar2ego`` etc.  Returns the same keys the reference puts into the sample."""
+    import os.path as osp
+    sensors = info["sensors"]
+    lidar2ego = sensors["LIDAR_TOP"]["lidar2ego"]
+    out = dict(img_filename=[], ego2img=[], lidar2img=[], lidar2cam=[], cam_intrinsic=[],
+               lidar2global=invert_pose(sensors["LIDAR_TOP"]["world2lidar"]))
+    for name, cam in sensors.items():
+        if "CAM" not in name:
+            continue
+        k = cam["intrinsic"]
+        k_pad = np.eye(4)
+        k_pad[:k.shape[0], :k.shape[1]] = k
+        ego2cam = invert_pose(cam["cam2ego"])
+        lidar2cam = ego2cam @ lidar2ego
+        out["img_filename"].append(osp.join(data_root, cam["data_path"]))
+        out["ego2img"].append(k_pad @ ego2cam)
+        out["lidar2img"].append(k_pad @ lidar2cam)
+        out["lidar2cam"].append(lidar2cam.T)
+        out["cam_intrinsic"].append(k_pad)
+    return out

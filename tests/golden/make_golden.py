@@ -570,6 +570,30 @@ def gen_pipeline():
         v = ad_out[k]
         v = v.data if isinstance(v, DC) else v
         out[f"adaptor_out_{k}"] = v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+    # ---- camera matrices of Bench2DriveDataset.get_data_info (bench2drive_dataset.py:763-805) on a made-up record ----
+    def pose(seed):
+        r = np.random.default_rng(seed)
+        q, _ = np.linalg.qr(r.normal(size=(3, 3)))
+        m = np.eye(4)
+        m[:3, :3], m[:3, 3] = q, r.normal(size=3) * 3
+        return m
+
+    sensors = {"LIDAR_TOP": dict(lidar2ego=pose(1), world2lidar=pose(2))}
+    for c in range(6):
+        sensors[f"CAM_{c}"] = dict(cam2ego=pose(10 + c), data_path=f"v1/cam{c}/00001.jpg",
+                                   intrinsic=np.array([[1142.5 + c, 0, 800], [0, 1142.5 + c, 450], [0, 0, 1.0]]))
+    sensors["RADAR_FRONT"] = dict(foo=1)
+    me = types.SimpleNamespace(data_infos=[dict(folder="town", frame_idx=7, sensors=sensors)], data_root="/data",
+                               modality=dict(use_camera=True), get_ann_info=lambda i: {})
+    me.invert_pose = lambda p: ds_mod.Bench2DriveDataset.invert_pose(me, p)
+    rec = ds_mod.Bench2DriveDataset.get_data_info(me, 0)
+    out["record_lidar2ego"], out["record_world2lidar"] = sensors["LIDAR_TOP"]["lidar2ego"], sensors["LIDAR_TOP"]["world2lidar"]
+    out["record_cam2ego"] = np.stack([sensors[f"CAM_{c}"]["cam2ego"] for c in range(6)])
+    out["record_intrinsic"] = np.stack([sensors[f"CAM_{c}"]["intrinsic"] for c in range(6)])
+    for k in ("ego2img", "lidar2img", "lidar2cam", "cam_intrinsic"):
+        out[f"record_out_{k}"] = np.stack(rec[k])
+    out["record_out_lidar2global"] = rec["lidar2global"]
+    out["record_out_img_filename"] = np.array(rec["img_filename"])
     # ---- sampler: 9 sequences of 3..11 frames, two ranks x batch 2, skipping and reversal on ----
     lens = [5, 3, 7, 4, 11, 6, 3, 8, 5]
     flag = np.concatenate([np.full(n, g) for g, n in enumerate(lens)])

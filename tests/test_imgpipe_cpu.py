@@ -193,3 +193,20 @@ def test_adaptor_step_equals_reference():
     stacked = torch.zeros(6, 3, 4, 5)
     assert NuScenesSparse4DAdaptor()(dict(lidar2img=list(G["lidar2img"]), img_shape=[(4, 5, 3)] * 6, lidar2global=np.eye(4),
                                          img=stacked))["img"] is stacked
+
+
+def test_camera_matrices_equal_reference_get_data_info():
+    """lidar2img / ego2img / lidar2cam / intrinsics / lidar2global of one annotation record, composed as
+    Bench2DriveDataset.get_data_info does (bit for bit: same float64 products in the same order)."""
+    from projects.mmdet3d_plugin.datasets import camera_matrices, invert_pose
+    sensors = {"LIDAR_TOP": dict(lidar2ego=G["record_lidar2ego"], world2lidar=G["record_world2lidar"])}
+    for c in range(6):
+        sensors[f"CAM_{c}"] = dict(cam2ego=G["record_cam2ego"][c], intrinsic=G["record_intrinsic"][c], data_path=f"v1/cam{c}/00001.jpg")
+    sensors["RADAR_FRONT"] = dict(foo=1)
+    rec = camera_matrices(dict(sensors=sensors), data_root="/data")
+    for k in ("ego2img", "lidar2img", "lidar2cam", "cam_intrinsic"):
+        assert np.array_equal(np.stack(rec[k]), G[f"record_out_{k}"]), k
+    assert np.array_equal(rec["lidar2global"], G["record_out_lidar2global"])
+    assert rec["img_filename"] == G["record_out_img_filename"].tolist()
+    p = G["record_cam2ego"][0]
+    assert np.allclose(invert_pose(p) @ p, np.eye(4), atol=1e-12)
