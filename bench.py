@@ -107,19 +107,21 @@ class DafStage2:
             d["kept_pairs"] = int(v.sum())
             d["rows_touched"] = self.unique_rows(d["loc"])
             self.calls.append(d)
+        self.rows_touched_frame = self.unique_rows([d["loc"] for d in self.calls])
 
     def unique_rows(self, loc):
-        """Distinct pyramid rows the in-bounds bilinear corners of ``loc`` touch (the kernels' own index work,
-        hipad_daf_taps): the compulsory pyramid traffic of a call is rows x 512 B (bf16 rows)."""
-        valid, taps = self.lib.daf_taps(self.ss, self.st, loc, self.F)
-        L = self.ss.shape[1]
-        h_low, w_low, mask, base = taps[..., 0].long(), taps[..., 1].long(), taps[..., 2], taps[..., 3].long()
-        W = self.ss[:, :, 1].long()[None, None, None]                       # (1,1,1,cams,L)
-        ok = valid.bool()[..., None]
+        """Distinct pyramid rows the in-bounds bilinear corners of ``loc`` (one location tensor, or a list of them:
+        the union) touch (the kernels' own index work, hipad_daf_taps): the compulsory pyramid traffic of a call is
+        rows x 512 B (bf16 rows)."""
         rows = []
-        for bit, (dh, dw) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
-            sel = ok & ((mask >> bit) & 1).bool()
-            rows.append((base + (h_low + dh) * W + (w_low + dw))[sel])
+        for one in (loc if isinstance(loc, (list, tuple)) else [loc]):
+            valid, taps = self.lib.daf_taps(self.ss, self.st, one, self.F)
+            h_low, w_low, mask, base = taps[..., 0].long(), taps[..., 1].long(), taps[..., 2], taps[..., 3].long()
+            W = self.ss[:, :, 1].long()[None, None, None]                       # (1,1,1,cams,L)
+            ok = valid.bool()[..., None]
+            for bit, (dh, dw) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+                sel = ok & ((mask >> bit) & 1).bool()
+                rows.append((base + (h_low + dh) * W + (w_low + dw))[sel])
         return int(torch.unique(torch.cat(rows)).numel())
 
     # -- algorithmic bytes (SURVEY.md section 8d) -------------------------------------------
@@ -136,12 +138,12 @@ class DafStage2:
             return wbytes + lbytes + obytes + fbytes
         if kind == "bwd_lw":   # reads w, loc, grad_out, feat; writes grad_w, grad_loc
             return (wbytes + lbytes + obytes + fbytes) + (wbytes + lbytes)
-        return wbytes + lbytes + obytes + 2 * (4 * 256 * d["rows_touched"])  # bwd_feat: read-modify-write of fp32 grad_feat rows
+        return wbytes + lbytes + obytes + 2 * (4 * 256 * d["rows_touched"])  # bwd_feat_single_call: read-modify-write of fp32 grad_feat rows
 
     def fwd(self, d):
         self.lib.daf_forward(self.feat, self.ss, self.st, d["loc"], d["w"], out=d["out"])
 
-    def bwd(self, d):
+    def bwd(self, d):  # one call's backward the reference's way: all three gradients by one call of the op
         self.lib.daf_backward(self.feat, self.ss, self.st, d["loc"], d["w"], d["gout"], self.gfeat, d["gloc"], d["gw"],
                               overwrite_loc_w=True)
 
@@ -149,8 +151,22 @@ class DafStage2:
         self.lib.daf_backward(self.feat, self.ss, self.st, d["loc"], d["w"], d["gout"], None, d["gloc"], d["gw"],
                               overwrite_loc_w=True)
 
-    def bwd_feat(self, d):  # grad_feat pipeline alone (count, alloc, place, gather)
+    def bwd_feat(self, d):  # grad_feat pipeline of ONE call (fill, count, alloc, place, accumulate)
         self.lib.daf_backward(self.feat, self.ss, self.st, d["loc"], d["w"], d["gout"], self.gfeat, None, None)
+
+    def bwd_feat_frame(self):
+        """The feature gradient of the frame's 24 calls the way the training step computes it: ONE counting sort + ONE
+        accumulation pass over the taps of all of them (hipad_daf_backward_feat_multi)."""
+        calls = [(d["loc"], d["w"], d["gout"]) for _ in range(self.LAYERS) for d in self.calls]
+        self.lib.daf_backward_feat_multi(calls, self.gfeat, self.ss, self.st)
+
+    def frame_feat_alg_bytes(self):
+        """Algorithmic bytes of bwd_feat_frame: every call's weights, locations and grad_out read once, and a
+        read-modify-write of every fp32 grad_feat row (1 KiB) that ANY of the calls touches -- once, not once per call."""
+        total = 0
+        for d in self.calls:
+            total += self.LAYERS * (4 * d["A"] * d["P"] * 6 * 4 * 8 + 4 * d["A"] * d["P"] * 6 * 2 + 4 * d["A"] * 256)
+        return total + 2 * 4 * 256 * self.rows_touched_frame
 
     def step(self):
         self.gfeat.zero_()  # one shared feature-gradient buffer per frame
@@ -159,22 +175,29 @@ class DafStage2:
                 self.fwd(d)
         for _ in range(self.LAYERS):
             for d in reversed(self.calls):
-                self.bwd(d)
+                self.bwd_lw(d)
+        self.bwd_feat_frame()
 
     def kernel_times(self, reps=20):
-        """Average launch duration (ms) of every (call, direction), HIP events on the launch stream."""
+        """Average launch duration (ms) of every (call, direction), HIP events on the launch stream; plus the frame's
+        merged feature-gradient pass (key ("frame", "bwd_feat"))."""
         res = {}
+
+        def timed(fn, *a):
+            fn(*a)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn(*a)
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / reps
+
         for d in self.calls:
-            for tag, fn in (("fwd", self.fwd), ("bwd_lw", self.bwd_lw), ("bwd_feat", self.bwd_feat)):
-                fn(d)
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(reps):
-                    fn(d)
-                e1.record()
-                e1.synchronize()
-                res[(d["name"], tag)] = e0.elapsed_time(e1) / reps
+            for tag, fn in (("fwd", self.fwd), ("bwd_lw", self.bwd_lw), ("bwd_feat_single_call", self.bwd_feat)):
+                res[(d["name"], tag)] = timed(fn, d)
+        res[("frame", "bwd_feat")] = timed(self.bwd_feat_frame)
         return res
 
     def cpu_baseline(self, seconds):
@@ -331,6 +354,7 @@ def _daf_grid_threads(A, P, cams=6, bs=1):
 
 
 PMC_FILE = "r02y_daf_pmc_traffic.json"
+MFMA_PMC_FILE = "r02a_linear_path_mfma_pmc.json"
 
 
 def pmc_traffic(kernel, A, P):
@@ -341,9 +365,7 @@ def pmc_traffic(kernel, A, P):
         return None
     with open(path) as f:
         table = json.load(f)["kernels"]
-    if kernel == "daf_bwd_feat_kernel":
-        # persistent grid (2048 x 256 threads) for every large call: the counters cannot tell the det / map / plan
-        # launches apart -- the figure is their average (traffic_source says so)
+    if kernel == "daf_bwd_feat_kernel":   # the frame's merged pass: one persistent grid (2048 x 256 threads)
         hit = table.get("hipad::daf_bwd_feat_kernel grid=524288")
     else:
         hit = table.get("hipad::%s grid=%d" % (kernel, _daf_grid_threads(A, P)))
@@ -353,33 +375,49 @@ def pmc_traffic(kernel, A, P):
 def roofline_of(daf, layers=6):
     """Dominant hand-written kernel of the step (largest per-frame time = launches x average duration), measured live
     with HIP events on the launch stream, against its algorithmic bytes; plus the same numbers for every other
-    aggregation launch (forward, grad loc+weights kernel, feature-gradient pipeline) of the four query sets."""
+    aggregation launch: forward and grad loc+weights kernel of the four query sets (6 launches per frame each), the
+    frame's merged feature-gradient pass (1 per frame), and -- for comparison, not part of the step any more -- the
+    feature-gradient pipeline of a single call."""
     kt = daf.kernel_times()
-    table = {}
+    table, per_frame = {}, {}
     for (name, tag), ms in kt.items():
-        dcall = next(d for d in daf.calls if d["name"] == name)
-        alg = daf.alg_bytes(dcall, tag)
+        if name == "frame":
+            alg, launches = daf.frame_feat_alg_bytes(), 1
+        else:
+            dcall = next(d for d in daf.calls if d["name"] == name)
+            alg, launches = daf.alg_bytes(dcall, tag.replace("_single_call", "")), layers
         gbs = alg / (ms * 1e-3) / 1e9
+        in_step = not tag.endswith("_single_call")
         table[f"{name}_{tag}"] = dict(ms=round(ms, 4), alg_mbytes=round(alg / 1e6, 1), GBs=round(gbs, 1),
-                                      frac=round(gbs / HBM_PEAK_GBS, 4), ms_per_frame=round(layers * ms, 3))
-    dom = max(kt, key=kt.get)
-    dcall = next(d for d in daf.calls if d["name"] == dom[0])
-    alg = daf.alg_bytes(dcall, dom[1])
-    achieved = alg / (kt[dom] * 1e-3) / 1e9
-    kname = {"fwd": "daf_fwd_c256_kernel<4, true> (+ combine)", "bwd_lw": "daf_bwd_lw_kernel<4, true, true>",
-             "bwd_feat": "feature-gradient pipeline (daf_tap_pass x2, daf_alloc, daf_bwd_feat_kernel)"}[dom[1]]
-    pmc_name = {"fwd": "daf_fwd_c256_kernel<4, true, unsigned short>",
-                "bwd_lw": "daf_bwd_lw_kernel<4, true, true, unsigned short>", "bwd_feat": "daf_bwd_feat_kernel"}[dom[1]]
-    return dict(bound="hbm", kernel=f"{kname} [{dom[0]}: A={dcall['A']} P={dcall['P']}]",
-                achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                traffic=pmc_traffic(pmc_name, dcall["A"], dcall["P"]),
+                                      frac=round(gbs / HBM_PEAK_GBS, 4),
+                                      ms_per_frame=round(launches * ms, 3) if in_step else None,
+                                      launches_per_frame=launches if in_step else 0)
+        if in_step:
+            per_frame[(name, tag)] = (launches * ms, alg, ms)
+    dom = max(per_frame, key=lambda k: per_frame[k][0])
+    _, alg, ms = per_frame[dom]
+    achieved = alg / (ms * 1e-3) / 1e9
+    if dom[0] == "frame":
+        kernel = ("feature-gradient pass of the frame's 24 aggregation calls (hipad_daf_backward_feat_multi: fill, "
+                  "daf_tap_pass x2, daf_alloc, daf_bwd_feat_kernel; one pass per frame)")
+        extra = dict(rows_touched=daf.rows_touched_frame, kept_pairs=layers * sum(d["kept_pairs"] for d in daf.calls))
+        traffic = pmc_traffic("daf_bwd_feat_kernel", None, None)
+        note_ = "; daf_bwd_feat_kernel only -- the payload kernel of the pass)"
+    else:
+        dcall = next(d for d in daf.calls if d["name"] == dom[0])
+        kname = {"fwd": "daf_fwd_c256_kernel<4, true> (+ combine)", "bwd_lw": "daf_bwd_lw_kernel<4, true, true>"}[dom[1]]
+        pmc_name = {"fwd": "daf_fwd_c256_kernel<4, true, unsigned short>",
+                    "bwd_lw": "daf_bwd_lw_kernel<4, true, true, unsigned short>"}[dom[1]]
+        kernel = f"{kname} [{dom[0]}: A={dcall['A']} P={dcall['P']}]"
+        extra = dict(rows_touched=dcall["rows_touched"], kept_pairs=dcall["kept_pairs"])
+        traffic = pmc_traffic(pmc_name, dcall["A"], dcall["P"])
+        note_ = ")"
+    return dict(bound="hbm", kernel=kernel, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                 traffic_source="profiles/" + PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                               "`bench.py --workload daf_stage2`, bytes per launch" +
-                               ("; daf_bwd_feat_kernel only -- the payload kernel of the pipeline -- averaged over the det / map / "
-                                "plan launches, which share one persistent grid)" if dom[1] == "bwd_feat" else ")"),
-                alg_bytes_per_launch=alg, avg_launch_ms=round(kt[dom], 4),
-                rows_touched=dcall["rows_touched"], kept_pairs=dcall["kept_pairs"],
-                aggregation_launches=table)
+                               "`bench.py --workload daf_stage2`, bytes per launch" + note_,
+                alg_bytes_per_launch=alg, avg_launch_ms=round(ms, 4), launches_per_frame=1 if dom[0] == "frame" else layers,
+                aggregation_launches=table, **extra)
 
 
 def self_launch(a):
@@ -481,7 +519,7 @@ def main():
                    roofline_scope="`roofline`: the aggregation launch with the largest per-frame time (live HIP-event timing, "
                                   "algorithmic bytes from the kernels' own tap indices); `roofline.frame`: sum over ALL "
                                   "operators of the step of max(bytes / 8 TB/s, flops / 2.5 PF) against the measured step; "
-                                  "MFMA utilisation of the linear path: profiles/r02_gemm_pmc.json")
+                                  "MFMA utilisation of the linear path: profiles/" + MFMA_PMC_FILE)
     elif infer:
         workload = ("stage2_infer: closed-loop style inference of hipad_b2d_stage2, batch 1, one 6-cam 704x256 frame per step: "
                     "encoder + decoder replayed from a hipGraph, then track ids and the result decoders (boxes, map vectors, "
@@ -492,15 +530,26 @@ def main():
     else:
         workload = ("daf_stage2: the 24 deformable-aggregation calls (6 layers x det 900x13, map 100x300, "
                     f"plan {a.plan_queries}x90, ego 1x13) fwd+bwd of one stage-2 frame, 6 cams 704x256, "
-                    "89760-position fp32 pyramid; aggregation path only (image encoder, attention/FFN "
-                    "and losses not included)")
-        dtype = "f32"
+                    "89760-position pyramid of bf16 rows (the encoder's output dtype) read in place, fp32 arithmetic, fp32 "
+                    "feature gradient; aggregation path only (image encoder, attention/FFN and losses not included)")
+        dtype = "f32"   # the arithmetic type of the path (rows are widened bf16 -> fp32 in registers)
         cfg = dict(workload=workload, frames_per_gpu_per_step=1, plan_queries=a.plan_queries, parallelism=f"dp{world}")
     out = dict(metric="frames/sec (6-cam 704x256, 900+100+6+48 queries) fwd+bwd at 1/2/4/8 GPUs",
                value=round(world * a.steps * (a.bs if full else 1) / dt, 3), unit="frames/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
                ms_per_step=round(dt / a.steps * 1e3, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
                dtype=dtype, data="synthetic", config=cfg, roofline=roof)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        # the measurement is complete here; the CPU leg below only adds `cpu_baseline`.  stdout carries exactly ONE JSON
+        # line (the contract), so the line as it stands goes to stderr and to gpurun_out/ first: a kill during the CPU
+        # leg (two round-2 runs ended there with an empty stdout) can no longer lose the GPU numbers.
+        partial = json.dumps(dict(out, cpu_baseline=None, partial="cpu_baseline leg still to run"))
+        print("[bench partial] " + partial, file=sys.stderr, flush=True)
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "bench_partial.json"), "w") as f:
+                f.write(partial + "\n")
+        except OSError:
+            pass
         note("cpu baseline ...")
         out["cpu_baseline"] = wl.cpu_frame_baseline(a.cpu_seconds) if full else daf.cpu_baseline(a.cpu_seconds)
     elif rank == 0:

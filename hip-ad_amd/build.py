@@ -39,7 +39,7 @@ def build_lib(force=False, verbose=False):
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
                 os.path.getmtime(src), *[os.path.getmtime(h) for h in
                                           glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))]):
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-fno-fast-math",
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-fno-fast-math", "-Wno-pass-failed",
                    "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", src, "-o", obj]
             if verbose:
                 cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

@@ -28,6 +28,7 @@
 // Steps 1-4 touch only index data + grad_out; step 5 re-gathers the features.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "hipad.h"
 #include "daf_common.h"
@@ -47,6 +48,43 @@ namespace hipad {
 // to global atomics.  Which maps are "coarse" is decided on device from spatial_shape: coarsest
 // level first while every camera's map of that level still fits the table.
 // ------------------------------------------------------------------------------------------
+// Multi-call form.  A decoder frame makes 24 aggregation calls whose feature gradients all land in ONE buffer, and the
+// pipeline above is pure fixed cost at the size of one call (five launches of a few dozen to a few hundred workgroups,
+// 2.4 ms per frame for 24 x 5 launches).  So the kernels take a TABLE of calls (location / weight / grad_out pointers and
+// the (anchors, points) of each; cameras, levels, the pyramid and grad_feat are shared): the (point,camera) pairs of all
+// calls form one global index space, a tap id is ((global pair * L + level) << 2) | corner, and count / alloc / place /
+// accumulate run ONCE per frame over every tap of the frame.  A row that several calls touch is read-modify-written
+// once instead of once per call.  The single-call entry (hipad_daf_backward) is the same code with a one-entry table.
+struct MultiArgs {
+  const float *loc[HIPAD_DAF_MAX_CALLS];
+  const float *wts[HIPAD_DAF_MAX_CALLS];
+  const float *gout[HIPAD_DAF_MAX_CALLS];
+  int A[HIPAD_DAF_MAX_CALLS];
+  int P[HIPAD_DAF_MAX_CALLS];
+  int pbase[HIPAD_DAF_MAX_CALLS + 1];  // first global pair of each call; pbase[ncalls] = all pairs
+  int ncalls;
+  int pad;
+};
+static_assert(sizeof(MultiArgs) % 4 == 0 && sizeof(MultiArgs) <= 3072, "kernel-argument budget");
+
+// the table, copied once per workgroup from the kernel-argument segment into LDS (runtime indexing of a by-value
+// argument would otherwise go through scratch)
+__device__ __forceinline__ void stage_calls(MultiArgs &lds, const MultiArgs &a) {
+  const unsigned *src = reinterpret_cast<const unsigned *>(&a);
+  unsigned *dst = reinterpret_cast<unsigned *>(&lds);
+  for (unsigned i = threadIdx.x; i < sizeof(MultiArgs) / 4; i += blockDim.x) dst[i] = src[i];
+}
+
+// call that owns global pair gp (pbase ascending, pbase[0] == 0, gp < pbase[ncalls])
+__device__ __forceinline__ int find_call(const int *pbase, int ncalls, int gp) {
+  int lo = 0, hi = ncalls - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (pbase[mid] <= gp) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
 constexpr int kTapBlock = 1024;
 constexpr int kLdsRows = 24576;  // 96 KiB of counters: all four levels of the six 704x256 cameras (22 440 rows).  With the
                                  // finest level left to global atomics the plan call's taps -- clustered on a few hundred
@@ -56,9 +94,11 @@ constexpr int kMaxMaps = 64;     // cams * L handled by the LDS path
 template <bool PLACE>
 __global__ __launch_bounds__(kTapBlock) void daf_tap_pass_kernel(
     int *__restrict__ counter /* cnt (count pass) or cursor (place pass) */, int *__restrict__ taps,
-    const int *__restrict__ ss, const int *__restrict__ start, const float *__restrict__ loc,
-    int npair, int cams, int num_feat, int L, int PA /* P*cams*A */, int cap /* slots in taps[] */) {
+    const int *__restrict__ ss, const int *__restrict__ start, const MultiArgs margs,
+    int npair, int cams, int num_feat, int L, int cap /* slots in taps[] */,
+    int nch /* chunks of kTapBlock consecutive pairs per workgroup */) {
   __shared__ int tab[kLdsRows];
+  __shared__ MultiArgs m;
   __shared__ int map_base[kMaxMaps];  // LDS slot of the map's first row, or -1
   // geometry of every (camera, level) map, fetched once by nmaps threads in parallel: thread 0's slot assignment,
   // the per-thread tap walks and the per-row flush all read it from LDS instead of chasing global loads
@@ -66,11 +106,14 @@ __global__ __launch_bounds__(kTapBlock) void daf_tap_pass_kernel(
   __shared__ int cm_slot[kMaxMaps + 1], cm_map[kMaxMaps];  // LDS-resident maps in slot order: first slot, map id
   __shared__ int used_s, ncoarse_s;
   const int tid = threadIdx.x;
-  const int pair = blockIdx.x * kTapBlock + tid;
   const int nmaps = cams * L;
   const bool lds_geo = nmaps <= kMaxMaps;
-  const int b0 = (blockIdx.x * kTapBlock) / PA;  // sample of the block's first pair
+  // A workgroup walks the pairs of ONE camera (blockIdx.y): its table then only has to hold that camera's maps, so
+  // at 704x256 all four levels are privatised (14 960 rows; the finest level of six cameras together is 67 584 and
+  // used to go tap by tap through global atomics: a quarter of all taps)
+  const int cam_b = blockIdx.y;
 
+  stage_calls(m, margs);
   if (lds_geo && tid < nmaps) {
     geo_h[tid] = ss[2 * tid];
     geo_w[tid] = ss[2 * tid + 1];
@@ -78,19 +121,22 @@ __global__ __launch_bounds__(kTapBlock) void daf_tap_pass_kernel(
   }
   if (tid < kMaxMaps) map_base[tid] = -1;
   __syncthreads();
+  // sample of the block's first pair (the LDS table privatises the rows of that sample)
+  const int q0 = blockIdx.x * kTapBlock * nch;      // first (anchor, point) of the block; pair = point * cams + camera
+  const int gp0 = q0 * cams + cam_b;
+  const int k0 = find_call(m.pbase, m.ncalls, min(gp0, npair - 1));
+  const int b0 = (gp0 - m.pbase[k0]) / (m.P[k0] * cams * m.A[k0]);
   if (tid == 0) {
     int used = 0, nc = 0;
     if (lds_geo) {
-      for (int s = L - 1; s >= 0; --s) {
-        int need = 0;
-        for (int c = 0; c < cams; ++c) need += geo_h[c * L + s] * geo_w[c * L + s];
+      for (int s = L - 1; s >= 0; --s) {    // coarsest level first, while the camera's map still fits
+        const int c = cam_b;
+        const int need = geo_h[c * L + s] * geo_w[c * L + s];
         if (used + need > kLdsRows) break;
-        for (int c = 0; c < cams; ++c) {
-          map_base[c * L + s] = used;
-          cm_slot[nc] = used;
-          cm_map[nc++] = c * L + s;
-          used += geo_h[c * L + s] * geo_w[c * L + s];
-        }
+        map_base[c * L + s] = used;
+        cm_slot[nc] = used;
+        cm_map[nc++] = c * L + s;
+        used += need;
       }
     }
     cm_slot[nc] = used;
@@ -102,21 +148,36 @@ __global__ __launch_bounds__(kTapBlock) void daf_tap_pass_kernel(
   for (int i = tid; i < used; i += kTapBlock) tab[i] = 0;
   __syncthreads();
 
-  float2 l = make_float2(-1.f, -1.f);
-  if (pair < npair) l = reinterpret_cast<const float2 *>(loc)[pair];
-  const bool kept = pair < npair && loc_kept(l.x, l.y);
-  const int cam = pair % cams;
-  const int b = pair / PA;
+  // the thread's pair of chunk c: location, camera, sample, kept
+  struct PairRef {
+    float2 l;
+    int pair, cam, b;
+    bool kept;
+  };
+  auto resolve = [&](int c) {
+    PairRef r;
+    r.pair = (q0 + c * kTapBlock + tid) * cams + cam_b;
+    r.l = make_float2(-1.f, -1.f);
+    const int kc = find_call(m.pbase, m.ncalls, min(r.pair, npair - 1));
+    const int lpair = r.pair - m.pbase[kc];  // pair index inside its call
+    if (r.pair < npair) r.l = reinterpret_cast<const float2 *>(m.loc[kc])[lpair];
+    r.kept = r.pair < npair && loc_kept(r.l.x, r.l.y);
+    r.cam = cam_b;                            // == lpair % cams: every call's pair count is a multiple of cams
+    r.b = lpair / (m.P[kc] * cams * m.A[kc]);
+    return r;
+  };
 
   // ---- phase 1: count into LDS (coarse maps of sample b0) or straight to global
-  if (kept) {
+  for (int c = 0; c < nch; ++c) {
+    const PairRef r = resolve(c);
+    if (!r.kept) continue;
     for (int s = 0; s < L; ++s) {
-      const int cs = cam * L + s;
+      const int cs = r.cam * L + s;
       const int H = lds_geo ? geo_h[cs] : ss[2 * cs], W = lds_geo ? geo_w[cs] : ss[2 * cs + 1];
-      const Taps t = make_taps(l.y, l.x, H, W);
-      const int lbase = (lds_geo && b == b0) ? map_base[cs] : -1;
-      const int gbase = b * num_feat + (lds_geo ? geo_s[cs] : start[cs]);
-      const int id0 = (pair * L + s) << 2;
+      const Taps t = make_taps(r.l.y, r.l.x, H, W);
+      const int lbase = (lds_geo && r.b == b0) ? map_base[cs] : -1;
+      const int gbase = r.b * num_feat + (lds_geo ? geo_s[cs] : start[cs]);
+      const int id0 = (r.pair * L + s) << 2;
 #pragma unroll
       for (int corner = 0; corner < 4; ++corner) {
         const bool in_h = (corner >> 1) ? t.in_h1 : t.in_h0;
@@ -172,14 +233,17 @@ __global__ __launch_bounds__(kTapBlock) void daf_tap_pass_kernel(
   if (!PLACE) return;
   __syncthreads();
   // ---- phase 3: draw slots from the LDS cursors
-  if (kept && b == b0 && lds_geo) {
+  if (!lds_geo) return;
+  for (int c = 0; c < nch; ++c) {
+    const PairRef r = resolve(c);
+    if (!(r.kept && r.b == b0)) continue;
     for (int s = 0; s < L; ++s) {
-      const int cs = cam * L + s;
+      const int cs = r.cam * L + s;
       const int lbase = map_base[cs];
       if (lbase < 0) continue;
       const int H = geo_h[cs], W = geo_w[cs];
-      const Taps t = make_taps(l.y, l.x, H, W);
-      const int id0 = (pair * L + s) << 2;
+      const Taps t = make_taps(r.l.y, r.l.x, H, W);
+      const int id0 = (r.pair * L + s) << 2;
 #pragma unroll
       for (int corner = 0; corner < 4; ++corner) {
         const bool in_h = (corner >> 1) ? t.in_h1 : t.in_h0;
@@ -240,39 +304,47 @@ __global__ __launch_bounds__(1024) void daf_alloc_kernel(int *__restrict__ cnt,
 __global__ __launch_bounds__(256) void daf_bwd_feat_kernel(
     float *__restrict__ gfeat, const int *__restrict__ taps, const int *__restrict__ offs,
     const int *__restrict__ ends /* cursor after placement */, const int *__restrict__ total_p,
-    const float *__restrict__ gout,
-    const float *__restrict__ loc, const float *__restrict__ wts, const int *__restrict__ ss,
-    const int *__restrict__ start, int R, int cams, int num_feat, int L, int A, int P, int npairL) {
+    const MultiArgs margs, const int *__restrict__ ss,
+    const int *__restrict__ start, int R, int cams, int num_feat, int L, int npairL) {
   __shared__ float wc_s[4][kWave][8];
+  __shared__ int htab[4][256];  // per wave: lowest lane of every hash bucket of (row, grad_out row) keys
+  __shared__ MultiArgs m;
   const int lane = threadIdx.x & (kWave - 1);
   const int wv = threadIdx.x >> 6;
+  stage_calls(m, margs);
+  __syncthreads();
   const int total = min(max(*total_p, 0), npairL * 4);  // never past the tap buffer, whatever the counter says
   const int nbatch = (total + kWave - 1) / kWave;
   const int nwaves = gridDim.x * 4;
   const int g = lane >> 3;  // group of this lane's 4 channels
-  const float4 *gout4 = reinterpret_cast<const float4 *>(gout);
   float4 *gfeat4 = reinterpret_cast<float4 *>(gfeat);
 
   for (int batch = uni(blockIdx.x * 4 + wv); batch < nbatch; batch += nwaves) {
     const int t0 = batch * kWave;
     const int n = min(kWave, total - t0);
     // ---- parallel decode: lane <-> tap
-    int row = -1, anchor = 0, excl = 0;
+    int row = -1, excl = 0;
+    // grad_out row of the tap's anchor (a 64-bit address in two lanes' registers: the calls' grad_out tensors are
+    // separate allocations); skipped slots keep the first call's first row, a legal address that is never used
+    unsigned long long grow = (unsigned long long)m.gout[0];
     float wq[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) wq[k] = 0.f;
     const int tap_id = lane < n ? taps[t0 + lane] : -1;
-    // a slot that is not a tap of THIS call (never expected: count and place walk the same pairs)
+    // a slot that is not a tap of THIS launch (never expected: count and place walk the same pairs)
     // must not be used as an index: it is skipped instead of trusted
     if (lane < n && tap_id >= 0 && (tap_id >> 2) < npairL) {
       const int id = tap_id;
       const int corner = id & 3;
       const int q = id >> 2;
-      const int pair = q / L, s = q - pair * L;
+      const int gpair = q / L, s = q - gpair * L;
+      const int kc = find_call(m.pbase, m.ncalls, gpair);
+      const int pair = gpair - m.pbase[kc];
       const int cam = pair % cams;
-      anchor = pair / (P * cams);
-      const int b = anchor / A;
-      const float2 l = reinterpret_cast<const float2 *>(loc)[pair];
+      const int anchor = pair / (m.P[kc] * cams);
+      const int b = anchor / m.A[kc];
+      grow = (unsigned long long)(m.gout[kc] + (size_t)anchor * 256);
+      const float2 l = reinterpret_cast<const float2 *>(m.loc[kc])[pair];
       const int cs = cam * L + s;
       const int H = ss[2 * cs], W = ss[2 * cs + 1];
       const Taps t = make_taps(l.y, l.x, H, W);
@@ -280,7 +352,7 @@ __global__ __launch_bounds__(256) void daf_bwd_feat_kernel(
       const float cw = (corner & 1) ? t.lw : t.hw;
       const float coef = ch * cw;
       row = b * num_feat + start[cs] + (t.h_low + (corner >> 1)) * W + (t.w_low + (corner & 1));
-      const float4 *w4 = reinterpret_cast<const float4 *>(wts) + (size_t)q * 2;
+      const float4 *w4 = reinterpret_cast<const float4 *>(m.wts[kc]) + ((size_t)pair * L + s) * 2;
       const float4 wa = w4[0], wb = w4[1];
       wq[0] = coef * wa.x; wq[1] = coef * wa.y; wq[2] = coef * wa.z; wq[3] = coef * wa.w;
       wq[4] = coef * wb.x; wq[5] = coef * wb.y; wq[6] = coef * wb.z; wq[7] = coef * wb.w;
@@ -289,10 +361,31 @@ __global__ __launch_bounds__(256) void daf_bwd_feat_kernel(
     __builtin_amdgcn_wave_barrier();
     reinterpret_cast<float4 *>(&wc_s[wv][lane][0])[0] = make_float4(wq[0], wq[1], wq[2], wq[3]);
     reinterpret_cast<float4 *>(&wc_s[wv][lane][0])[1] = make_float4(wq[4], wq[5], wq[6], wq[7]);
+    reinterpret_cast<int4 *>(&htab[wv][0])[lane] = make_int4(kWave, kWave, kWave, kWave);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    // ---- walk the batch (row < 0 marks a skipped slot: contributes nothing, is never flushed)
+    // ---- merge the taps of the batch that hit the same row FROM the same grad_out row (the points of one anchor
+    // crowd into few pixels of the coarse levels: 2-4 taps per such pair on a stage-2 frame): their coefficients add,
+    // and ONE 1 KiB grad_out load serves them all -- the pass is bound by exactly those loads.  Leader = the lowest lane
+    // of the key's hash bucket; a bucket shared by different keys merges nothing (each lane stays its own leader).
+    const int grow_lo = (int)(unsigned)(grow & 0xffffffffull), grow_hi = (int)(unsigned)(grow >> 32);
+    const unsigned hb = (((unsigned)row * 0x9E3779B1u) ^ ((unsigned)grow_lo * 0x85EBCA6Bu)) >> 24;
+    if (row >= 0) atomicMin(&htab[wv][hb], lane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int cand = row >= 0 ? htab[wv][hb] : lane;
+    const bool same = __shfl(row, cand) == row && __shfl(grow_lo, cand) == grow_lo && __shfl(grow_hi, cand) == grow_hi;
+    const int leader = (row >= 0 && same) ? cand : lane;
+    if (leader != lane) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) atomicAdd(&wc_s[wv][leader][k], wq[k]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long live = __ballot(row >= 0 && leader == lane);
+
+    // ---- walk the leaders (rows ascend with the lane index: a merged tap belongs to its leader's row)
     auto flush = [&](int r, int ex, const float4 &o, const float4 &a4) {
       if (r < 0) return;
       float4 *p = gfeat4 + (size_t)r * 64 + lane;
@@ -303,46 +396,53 @@ __global__ __launch_bounds__(256) void daf_bwd_feat_kernel(
         atomicAdd(pf + 0, a4.x); atomicAdd(pf + 1, a4.y); atomicAdd(pf + 2, a4.z); atomicAdd(pf + 3, a4.w);
       }
     };
-    int cur = rl_i(row, 0);
-    int cur_excl = rl_i(excl, 0);
+    int cur = -1, cur_excl = 0;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 old = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (cur >= 0 && cur_excl) old = gfeat4[(size_t)cur * 64 + lane];
     // kAhead grad_out rows in flight: with one load per iteration behind the row-change branch every tap paid a full
-    // memory latency (64 of them per batch)
-    constexpr int kAhead = 8;
-    for (int tb = 0; tb < n; tb += kAhead) {
-      float4 gq[kAhead], oq[kAhead];
+    // memory latency.  The row's present value is fetched when the row starts and wanted only when it ends.
+    // Measured on the frame pass (tools/sweep_tap_chunks.py): 4 ahead 830 us, 8 ahead 870 (the last trip of a batch
+    // loads rows nobody uses), 16 ahead 860; a wave-uniform `if` around each load 2 000 us (a wait per load).
+#ifndef HIPAD_FEAT_AHEAD
+#define HIPAD_FEAT_AHEAD 4
+#endif
+    constexpr int kAhead = HIPAD_FEAT_AHEAD;
+    while (live) {
+      int idx[kAhead];
+      unsigned long long mm = live;
+#pragma unroll
+      for (int k = 0; k < kAhead; ++k) {
+        idx[k] = mm ? (int)__builtin_ctzll(mm) : -1;
+        mm = mm ? (mm & (mm - 1)) : 0ull;
+      }
+      float4 gq[kAhead];
       float wq8[kAhead];
 #pragma unroll
       for (int k = 0; k < kAhead; ++k) {
-        const int tt = min(tb + k, n - 1);
-        gq[k] = gout4[(size_t)rl_i(anchor, tt) * 64 + lane];
-        // the row's present value as well: most rows hold one or two taps, and a load issued at the row's first tap
-        // is wanted back at its last -- one exposed memory latency per row.  (Rows are sorted: a row's first tap
-        // is loaded before anything of this batch is stored to it.)
-        oq[k] = gfeat4[(size_t)max(rl_i(row, tt), 0) * 64 + lane];
+        const int tt = idx[k] >= 0 ? idx[k] : idx[0];
+        const unsigned long long ga = ((unsigned long long)(unsigned)rl_i(grow_hi, tt) << 32) | (unsigned)rl_i(grow_lo, tt);
+        gq[k] = reinterpret_cast<const float4 *>(ga)[lane];
         wq8[k] = wc_s[wv][tt][g];
       }
 #pragma unroll
       for (int k = 0; k < kAhead; ++k) {
-        const int t = tb + k;
-        if (t < n) {
-          const int rt = rl_i(row, t);
+        if (idx[k] >= 0) {
+          const int rt = rl_i(row, idx[k]);
           if (rt != cur) {
             flush(cur, cur_excl, old, acc);
             cur = rt;
-            cur_excl = rl_i(excl, t);
+            cur_excl = rl_i(excl, idx[k]);
             acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            old = oq[k];
+            if (cur_excl) old = gfeat4[(size_t)cur * 64 + lane];
           }
           const float wc = wq8[k];
           acc.x += wc * gq[k].x; acc.y += wc * gq[k].y; acc.z += wc * gq[k].z; acc.w += wc * gq[k].w;
         }
       }
+      live = mm;
     }
     flush(cur, cur_excl, old, acc);
-    __builtin_amdgcn_wave_barrier();  // wc_s[wv] is rewritten by the next batch
+    __builtin_amdgcn_wave_barrier();  // wc_s[wv] / htab[wv] are rewritten by the next batch
   }
 }
 
@@ -489,6 +589,9 @@ __global__ __launch_bounds__(256) void daf_bwd_lw_kernel(
 }
 
 // ----------------------------------------------------------------------------- host side
+static int g_tap_chunks = 0;  // 0 = automatic
+void daf_set_tap_chunks(int n) { g_tap_chunks = n > 0 ? n : 0; }
+
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct SortedWs {
@@ -496,9 +599,9 @@ struct SortedWs {
   size_t bytes;
 };
 
-static SortedWs carve(const DafDims &d, void *base) {
-  const size_t R = (size_t)d.bs * d.num_feat;
-  const size_t tmax = (size_t)d.bs * d.A * d.P * d.cams * d.L * 4;
+// R pyramid rows (all samples), npair (point,camera) pairs over all calls
+static SortedWs carve(size_t R, size_t npair, int L, void *base) {
+  const size_t tmax = npair * L * 4;
   char *p = (char *)base;
   SortedWs w;
   size_t o = 0;
@@ -510,43 +613,117 @@ static SortedWs carve(const DafDims &d, void *base) {
   return w;
 }
 
+static bool sorted_budget_ok(long long bs, long long num_feat, long long npair, int L) {
+  return npair * L * 4 < (1ll << 31) && bs * num_feat < (1ll << 30);
+}
+
 bool daf_bwd_sorted_supported(const DafDims &d) {
   if (d.C != 256 || d.G != 8 || d.L > 8) return false;
-  const long long tmax = (long long)d.bs * d.A * d.P * d.cams * d.L * 4;
-  return tmax < (1ll << 31) && (long long)d.bs * d.num_feat < (1ll << 30);
+  return sorted_budget_ok(d.bs, d.num_feat, (long long)d.bs * d.A * d.P * d.cams, d.L);
 }
 
 size_t daf_bwd_sorted_workspace(const DafDims &d) {
   if (!daf_bwd_sorted_supported(d)) return 0;
-  return carve(d, nullptr).bytes;
+  return carve((size_t)d.bs * d.num_feat, (size_t)d.bs * d.A * d.P * d.cams, d.L, nullptr).bytes;
+}
+
+// the pipeline over a table of calls (m.pbase filled in by the caller)
+static int run_sorted(const MultiArgs &m, const int *ss, const int *start, float *gfeat, int bs, int cams, int num_feat,
+                      int L, void *workspace, size_t workspace_bytes, hipStream_t stream) {
+  const int npair = m.pbase[m.ncalls];
+  const int R = bs * num_feat;
+  const SortedWs w = carve((size_t)R, (size_t)npair, L, workspace);
+  if (!workspace || workspace_bytes < w.bytes) return HIPAD_EWORKSPACE;
+  if (fill_zero(w.cnt, (size_t)(R + 1) * 4, stream) != HIPAD_OK) return HIPAD_ELAUNCH;
+  // Work split of the two tap passes: blockIdx.y = camera, blockIdx.x = a run of `nch` chunks of 1024 consecutive
+  // (anchor, point) indices.  Every workgroup clears and flushes its LDS table once whatever it walks, and pays one global
+  // atomic per pyramid row it touches: fewer, longer workgroups mean fewer of those (a frame: 1.5 M at 252 workgroups),
+  // more workgroups mean a shorter walk -- about three per CU is the default, hipad_daf_set_tap_chunks() overrides it.
+  const int npoint = npair / cams;
+  int nch = g_tap_chunks;
+  if (nch <= 0) {
+    const long long per_cam = 768 / cams > 0 ? 768 / cams : 1;   // ~3 workgroups per CU (measured: tools/sweep_tap_chunks.py)
+    nch = (int)(((long long)npoint + (long long)kTapBlock * per_cam - 1) / ((long long)kTapBlock * per_cam));
+  }
+  nch = nch < 1 ? 1 : (nch > 64 ? 64 : nch);
+  const dim3 pg((npoint + kTapBlock * nch - 1) / (kTapBlock * nch), cams), pb(kTapBlock);
+  const int cap = npair * L * 4;
+  hipLaunchKernelGGL(daf_tap_pass_kernel<false>, pg, pb, 0, stream, w.cnt, (int *)nullptr, ss, start, m, npair, cams,
+                     num_feat, L, cap, nch);
+  hipLaunchKernelGGL(daf_alloc_kernel, dim3((R + 1023) / 1024), dim3(1024), 0, stream, w.cnt, w.offs,
+                     w.cursor, R);
+  hipLaunchKernelGGL(daf_tap_pass_kernel<true>, pg, pb, 0, stream, w.cursor, w.taps, ss, start, m, npair, cams,
+                     num_feat, L, cap, nch);
+  // persistent grid: up to 2048 blocks x 4 waves walk the batches of 64 taps
+  const long long tmax = (long long)npair * L * 4;
+  long long nb = (tmax + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(daf_bwd_feat_kernel, dim3((unsigned)nb), dim3(256), 0, stream, gfeat, (const int *)w.taps,
+                     (const int *)w.offs, (const int *)w.cursor, (const int *)(w.cnt + R), m, ss, start, R, cams, num_feat,
+                     L, npair * L);
+  return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
 }
 
 int daf_bwd_sorted_feat(const float *, const int *ss, const int *start, const float *loc,
                         const float *wts, const float *gout, float *gfeat, const DafDims &d,
                         void *workspace, size_t workspace_bytes, hipStream_t stream) {
   if (!daf_bwd_sorted_supported(d)) return HIPAD_EINVAL;
-  const SortedWs w = carve(d, workspace);
-  if (!workspace || workspace_bytes < w.bytes) return HIPAD_EWORKSPACE;
-  const int R = d.bs * d.num_feat;
-  const int npair = d.bs * d.A * d.P * d.cams;
-  if (fill_zero(w.cnt, (size_t)(R + 1) * 4, stream) != HIPAD_OK) return HIPAD_ELAUNCH;
-  const dim3 pg((npair + kTapBlock - 1) / kTapBlock), pb(kTapBlock);
-  const int cap = npair * d.L * 4;
-  hipLaunchKernelGGL(daf_tap_pass_kernel<false>, pg, pb, 0, stream, w.cnt, (int *)nullptr, ss, start, loc,
-                     npair, d.cams, d.num_feat, d.L, d.P * d.cams * d.A, cap);
-  hipLaunchKernelGGL(daf_alloc_kernel, dim3((R + 1023) / 1024), dim3(1024), 0, stream, w.cnt, w.offs,
-                     w.cursor, R);
-  hipLaunchKernelGGL(daf_tap_pass_kernel<true>, pg, pb, 0, stream, w.cursor, w.taps, ss, start, loc, npair,
-                     d.cams, d.num_feat, d.L, d.P * d.cams * d.A, cap);
-  // persistent grid: 2048 blocks x 4 waves walk the batches of 64 taps
-  const long long tmax = (long long)npair * d.L * 4;
-  long long nb = (tmax + 255) / 256;
-  if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL(daf_bwd_feat_kernel, dim3((unsigned)nb), dim3(256), 0, stream, gfeat, (const int *)w.taps,
-                     (const int *)w.offs, (const int *)w.cursor, (const int *)(w.cnt + R), gout, loc, wts, ss, start, R, d.cams, d.num_feat,
-                     d.L, d.A, d.P, npair * d.L);
-  return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
+  MultiArgs m;
+  memset(&m, 0, sizeof(m));
+  m.loc[0] = loc; m.wts[0] = wts; m.gout[0] = gout;
+  m.A[0] = d.A; m.P[0] = d.P;
+  m.pbase[0] = 0; m.pbase[1] = d.bs * d.A * d.P * d.cams;
+  m.ncalls = 1;
+  return run_sorted(m, ss, start, gfeat, d.bs, d.cams, d.num_feat, d.L, workspace, workspace_bytes, stream);
 }
+
+static int multi_table(MultiArgs &m, const hipad_daf_call *calls, int ncalls, int bs, int cams, int num_feat, int C,
+                       int L, int G) {
+  if (!calls || ncalls <= 0 || ncalls > HIPAD_DAF_MAX_CALLS) return HIPAD_EINVAL;
+  if (bs <= 0 || cams <= 0 || num_feat <= 0 || L <= 0 || L > 8 || C != 256 || G != 8) return HIPAD_EINVAL;
+  memset(&m, 0, sizeof(m));
+  long long total = 0;
+  for (int k = 0; k < ncalls; ++k) {
+    const hipad_daf_call &c = calls[k];
+    if (!c.loc || !c.weights || !c.grad_out || c.num_anchors <= 0 || c.num_pts <= 0) return HIPAD_EINVAL;
+    m.loc[k] = c.loc; m.wts[k] = c.weights; m.gout[k] = c.grad_out;
+    m.A[k] = c.num_anchors; m.P[k] = c.num_pts;
+    m.pbase[k] = (int)total;
+    total += (long long)bs * c.num_anchors * c.num_pts * cams;
+    if (!sorted_budget_ok(bs, num_feat, total, L)) return HIPAD_ERANGE;
+  }
+  m.pbase[ncalls] = (int)total;
+  m.ncalls = ncalls;
+  return HIPAD_OK;
+}
+
+}  // namespace hipad
+
+extern "C" {
+
+void hipad_daf_set_tap_chunks(int chunks) { hipad::daf_set_tap_chunks(chunks); }
+
+size_t hipad_daf_backward_feat_multi_workspace(const hipad_daf_call *calls, int ncalls, int bs, int cams, int num_feat,
+                                               int C, int L, int G) {
+  hipad::MultiArgs m;
+  if (hipad::multi_table(m, calls, ncalls, bs, cams, num_feat, C, L, G) != HIPAD_OK) return 0;
+  return hipad::carve((size_t)bs * num_feat, (size_t)m.pbase[ncalls], L, nullptr).bytes;
+}
+
+int hipad_daf_backward_feat_multi(const hipad_daf_call *calls, int ncalls, float *grad_feat, const int32_t *spatial_shape,
+                                  const int32_t *scale_start_index, int bs, int cams, int num_feat, int C, int L, int G,
+                                  void *workspace, size_t workspace_bytes, hipad_stream_t stream) {
+  hipad::MultiArgs m;
+  const int rc = hipad::multi_table(m, calls, ncalls, bs, cams, num_feat, C, L, G);
+  if (rc != HIPAD_OK) return rc;
+  if (!grad_feat || !spatial_shape || !scale_start_index) return HIPAD_EINVAL;
+  return hipad::run_sorted(m, spatial_shape, scale_start_index, grad_feat, bs, cams, num_feat, L, workspace,
+                           workspace_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+namespace hipad {
 
 int daf_bwd_lw(const void *feat, bool feat_bf16, const int *ss, const int *start, const float *loc, const float *wts,
                const float *gout, float *gloc, float *gw, const DafDims &d, int nchunks, int ppc,

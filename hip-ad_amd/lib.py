@@ -25,6 +25,10 @@ SIGNATURES = {
     "hipad_daf_backward_workspace": (c_size_t, [c_int] * 8),
     "hipad_daf_backward": (c_int, [c_void_p] * 9 + [c_int] * 8 + [c_int, c_void_p, c_size_t, c_void_p]),
     "hipad_daf_taps": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
+    "hipad_daf_set_tap_chunks": (None, [c_int]),
+    "hipad_daf_backward_feat_multi_workspace": (c_size_t, [c_void_p, c_int] + [c_int] * 6),
+    "hipad_daf_backward_feat_multi": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 6
+                                      + [c_void_p, c_size_t, c_void_p]),
     "hipad_project_points_forward": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "hipad_project_points_backward": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "hipad_weights_softmax_forward": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
@@ -196,6 +200,50 @@ def daf_backward(feat, spatial_shape, scale_start_index, loc, weights, grad_out,
             *d, flags, ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
             stream_ptr(feat.device))
     check(st, "hipad_daf_backward")
+
+
+class DafCall(ctypes.Structure):
+    """include/hipad.h: hipad_daf_call."""
+    _fields_ = [("loc", c_void_p), ("weights", c_void_p), ("grad_out", c_void_p),
+                ("num_anchors", ctypes.c_int32), ("num_pts", ctypes.c_int32)]
+
+
+DAF_MAX_CALLS = 64
+
+
+def daf_backward_feat_multi(calls, grad_feat, spatial_shape, scale_start_index):
+    """grad_feat (bs, num_feat, 256) fp32 += the feature gradient of every (loc, weights, grad_out) triple of ``calls``
+    -- hipad_daf_backward_feat_multi: one counting sort + one accumulation pass for all of them (tables of more than
+    DAF_MAX_CALLS entries are worked off in several passes)."""
+    lib = load()
+    _req(grad_feat, torch.float32, "grad_feat"); _req(spatial_shape, torch.int32, "spatial_shape")
+    _req(scale_start_index, torch.int32, "scale_start_index")
+    bs, num_feat, C = grad_feat.shape
+    cams, L = spatial_shape.shape[:2]
+    dev = grad_feat.device
+    for lo in range(0, len(calls), DAF_MAX_CALLS):
+        part = calls[lo:lo + DAF_MAX_CALLS]
+        table = (DafCall * len(part))()
+        G = None
+        for k, (loc, w, gout) in enumerate(part):
+            _req(loc, torch.float32, "sampling_location"); _req(w, torch.float32, "weights"); _req(gout, torch.float32, "grad_output")
+            A, P = loc.shape[1:3]
+            G = w.shape[5]
+            if tuple(loc.shape) != (bs, A, P, cams, 2) or tuple(w.shape) != (bs, A, P, cams, L, G) \
+                    or tuple(gout.shape) != (bs, A, C):
+                raise HipadError(f"daf_backward_feat_multi: call {lo + k} has loc{tuple(loc.shape)} weights{tuple(w.shape)} "
+                                 f"grad_out{tuple(gout.shape)} for bs={bs} cams={cams} L={L} C={C}")
+            table[k] = DafCall(loc.data_ptr(), w.data_ptr(), gout.data_ptr(), A, P)
+        dims = (bs, cams, num_feat, C, L, G)
+        nbytes = lib.hipad_daf_backward_feat_multi_workspace(ctypes.addressof(table), len(part), *dims)
+        if not nbytes:
+            raise HipadError(f"daf_backward_feat_multi: unsupported shapes {dims} ({len(part)} calls)")
+        ws = _workspace(nbytes, dev)
+        with torch.cuda.device(dev):
+            st = lib.hipad_daf_backward_feat_multi(ctypes.addressof(table), len(part), grad_feat.data_ptr(),
+                                                   spatial_shape.data_ptr(), scale_start_index.data_ptr(), *dims,
+                                                   ws.data_ptr(), ws.numel(), stream_ptr(dev))
+        check(st, "hipad_daf_backward_feat_multi")
 
 
 def daf_taps(spatial_shape, scale_start_index, loc, num_feat):

@@ -122,6 +122,42 @@ int hipad_daf_backward_bf16(const void *feat_bf16, const int32_t *spatial_shape,
                             size_t workspace_bytes, hipad_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Feature gradient of SEVERAL aggregation calls in one pass (ours; the reference runs
+ * deformable_aggregation_grad once per call site, ops/deformable_aggregation.py:41-75, each time zero-filling and
+ * scattering into a fresh copy of the pyramid that autograd then adds up: 24 call sites per decoder forward,
+ * models/sparse_onedecoder.py:867-887).
+ * The calls share the pyramid geometry (batch_size, cams, num_feat, levels, 256 channels, 8 groups) and therefore the
+ * feature-gradient buffer; each brings its own sampling locations, weights and output gradient:
+ *   calls[k].loc      [bs, A_k, P_k, cams, 2] f32      calls[k].weights [bs, A_k, P_k, cams, L, 8] f32
+ *   calls[k].grad_out [bs, A_k, 256] f32
+ * grad_feat [bs, num_feat, 256] f32 is ACCUMULATED into, exactly as by `ncalls` calls of hipad_daf_backward with
+ * grad_loc = grad_w = NULL (same taps, same products; the summation order inside a row differs, as it does between any
+ * two runs of the reference's atomics).  One counting sort of the bilinear taps of ALL calls by pyramid row, one
+ * accumulation pass: a row touched by several calls is read-modified-written once.
+ * `calls` is a HOST array (ncalls <= HIPAD_DAF_MAX_CALLS); it is copied into the kernel arguments, the tensors it
+ * points to must stay valid until the launches have run.  workspace: hipad_daf_backward_feat_multi_workspace() bytes.
+ * ---------------------------------------------------------------------------------- */
+#define HIPAD_DAF_MAX_CALLS 64
+typedef struct hipad_daf_call {
+  const float *loc;
+  const float *weights;
+  const float *grad_out;
+  int32_t num_anchors;
+  int32_t num_pts;
+} hipad_daf_call;
+
+/* Tuning knob of the counting sort (like hipad_daf_set_pairs_per_wave): chunks of 1024 (anchor, point) indices one
+ * workgroup of the tap passes walks; 0 = automatic (about one workgroup per CU). */
+void hipad_daf_set_tap_chunks(int chunks);
+
+size_t hipad_daf_backward_feat_multi_workspace(const hipad_daf_call *calls, int ncalls, int batch_size, int num_cams,
+                                               int num_feat, int num_embeds, int num_scale, int num_groups);
+int hipad_daf_backward_feat_multi(const hipad_daf_call *calls, int ncalls, float *grad_feat,
+                                  const int32_t *spatial_shape, const int32_t *scale_start_index, int batch_size,
+                                  int num_cams, int num_feat, int num_embeds, int num_scale, int num_groups,
+                                  void *workspace, size_t workspace_bytes, hipad_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Index work of the operator, exposed for bit-exact checks (no reference counterpart as a
  * function: it is the integer part of deformable_aggregation_cuda.cu:160-181 + :18-52).
  *   valid [bs*A*P*cams] u8;  taps [bs*A*P*cams*scales*4] i32 = (h_low, w_low, mask, row)

@@ -85,6 +85,11 @@ def _merge_groups(parts):
 
 
 def _inverse(col_feats, spatial_shape, scale_start_index):
+    levels = getattr(col_feats, "_hipad_levels", None)
+    if levels is not None:
+        # the detector's own level tensors ride on the flat tensor it made from them (same values): handing them back
+        # keeps the consumers' gradient on the (small) levels instead of a slice of a pyramid-sized zero tensor
+        return [list(levels)]
     host = getattr(spatial_shape, "_hipad_host", None)
     if host is None:
         host = spatial_shape.tolist()  # foreign tensor: one device->host copy

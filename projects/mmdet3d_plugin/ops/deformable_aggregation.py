@@ -9,7 +9,11 @@ Differences underneath (same results):
     re-cast by a kernel on each of the 24 calls per forward;
   * backward lets the kernel write grad_location / grad_weights outright (no memsets);
   * if the feature tensor came through ``shared_feature_grad`` the 24 call sites add their
-    feature gradient into ONE buffer instead of 24x (zeros + autograd add) of the pyramid.
+    feature gradient into ONE buffer instead of 24x (zeros + autograd add) of the pyramid -- and they do it in ONE
+    pass: each call's backward only computes grad_location / grad_weights and leaves its (location, weights,
+    grad_output) triple with the sink, whose own backward node (it runs after every call's) hands the whole table to
+    ``hipad_daf_backward_feat_multi``: one counting sort + one accumulation for the frame instead of 24 five-launch
+    pipelines (``HIPAD_DAF_DEFER=0`` restores the per-call pipelines).
 """
 import torch
 from torch.autograd.function import Function, once_differentiable
@@ -20,6 +24,7 @@ from hipad_amd import lib as _lib
 import os as _os
 
 _ATOMIC_FEAT = _os.environ.get("HIPAD_DAF_ATOMIC", "0") == "1"  # debugging aid: one-pass atomic scatter backward
+DEFER_FEAT = _os.environ.get("HIPAD_DAF_DEFER", "1") == "1"      # feature gradient of all call sites in one pass (sink)
 
 
 _CROSS_CHECK = _os.environ.get("HIPAD_DAF_CROSS_CHECK", "0") == "1"  # debugging aid, see _cross_check
@@ -76,7 +81,10 @@ class _FeatureGradSink(Function):
     @staticmethod
     def forward(ctx, feat):
         out = feat.view_as(feat)
-        ctx.holder = holder = {"bufs": {}}  # one accumulation buffer per stream that runs aggregation backwards
+        ctx.set_materialize_grads(False)    # no direct consumer of `out` -> grad_feat arrives as None, not as zeros
+        # "bufs": one accumulation buffer per stream that runs aggregation backwards (per-call pipelines);
+        # "pending": the (feat, ss, st, loc, w, grad_out) of the call sites whose feature gradient is deferred to this node
+        ctx.holder = holder = {"bufs": {}, "pending": []}
         out._hipad_grad_holder = holder
         token = torch.zeros((), dtype=feat.dtype, device=feat.device)
         holder["zero"] = token.detach()     # the (constant) gradient every consumer returns for its token edge
@@ -86,8 +94,15 @@ class _FeatureGradSink(Function):
     def backward(ctx, grad_feat, grad_token):
         bufs = list(ctx.holder["bufs"].values())
         ctx.holder["bufs"] = {}
+        pending, ctx.holder["pending"] = ctx.holder["pending"], []
+        if pending:
+            feat, ss, st = pending[0][:3]
+            buf = bufs[0] if bufs else torch.zeros(feat.shape, dtype=torch.float32, device=feat.device)
+            if not bufs:
+                bufs = [buf]
+            _lib.daf_backward_feat_multi([c[3:] for c in pending], buf, ss, st)
         total = grad_feat
-        here = torch.cuda.current_stream(grad_token.device) if grad_token.is_cuda else None
+        here = torch.cuda.current_stream(grad_token.device) if (grad_token is not None and grad_token.is_cuda) else None
         for buf in bufs:  # the token edges made the engine order this node after every producer stream
             if here is not None:
                 buf.record_stream(here)
@@ -133,7 +148,16 @@ class DeformableAggregationFunction(Function):
         grad_w = torch.empty_like(w) if need_w else None
         grad_feat = ret_feat = None
         grad_token = None
-        if ctx.holder is not None:
+        deferrable = (DEFER_FEAT and not _ATOMIC_FEAT and not _CROSS_CHECK and feat.is_cuda and feat.shape[-1] == 256
+                      and w.shape[-1] == 8 and ss.shape[1] <= 8)
+        if ctx.holder is not None and deferrable:
+            # the sink's backward runs the feature gradient of ALL call sites in one pass (see the module docstring); the
+            # token edge orders that node behind this one, on whatever stream this one ran
+            ctx.holder["pending"].append((feat, ss, st, loc, w, grad_output))
+            grad_token = ctx.holder.get("zero")
+            if grad_token is None:
+                grad_token = torch.zeros((), dtype=feat.dtype, device=feat.device)
+        elif ctx.holder is not None:
             # shared sink: every call site running on THIS stream adds into the same buffer (calls on one stream
             # are serialised; concurrent streams get a buffer each: the kernel's read-modify-write of rows is
             # exclusive only within a launch); the sink node sums the buffers

@@ -283,3 +283,69 @@ def test_bf16_feature_rows_are_bit_identical_to_the_widened_tensor(lib, kind):
     from hipad_amd.lib import HipadError
     with pytest.raises(HipadError):
         lib.daf_forward(feat16[..., :128].contiguous(), ss, st, loc, w[..., :4].contiguous())
+
+
+# ---- feature gradient of several call sites in one pass (hipad_daf_backward_feat_multi) -------------------------------
+MULTI_SHAPES = [(16, 44), (8, 22), (4, 11), (2, 6)]
+
+
+def _multi_calls(bs, specs, seed=70):
+    """Calls (different anchors x points each) on ONE pyramid geometry: [(loc, w, gout)], plus the shared tables."""
+    calls, ss, st, feat = [], None, None, None
+    for k, (A, P) in enumerate(specs):
+        f, ss, st, loc, w, gout = make_inputs(seed + k, bs, A, P, MULTI_SHAPES)
+        feat = f if feat is None else feat
+        calls.append((loc, w, gout))
+    return feat, ss, st, calls
+
+
+@pytest.mark.parametrize("bs", [1, 2])
+def test_feat_multi_vs_cpu_oracle(lib, bs):
+    """The frame's mix of call shapes (det / map / plan / ego point counts) through ONE sorted pass equals the sum of
+    the oracle's per-call feature gradients; grad_feat is accumulated into (starts non-zero)."""
+    feat, ss, st, calls = _multi_calls(bs, [(37, 13), (5, 300), (9, 90), (1, 13), (37, 13)])
+    ref = np.zeros(feat.shape, np.float64)
+    for loc, w, gout in calls:
+        ref += O.daf_backward(feat.numpy(), ss, st, loc.numpy(), w.numpy(), gout.numpy(), acc64=True)[0]
+    gf = torch.ones(feat.shape, device="cuda")
+    lib.daf_backward_feat_multi([tuple(t.cuda() for t in c) for c in calls], gf, torch.from_numpy(ss).cuda(),
+                                torch.from_numpy(st).cuda())
+    assert rel_err(gf - 1, ref) < 1e-5
+
+
+def test_feat_multi_equals_per_call_launches_and_chunks_long_tables(lib):
+    """Same taps, same products as one hipad_daf_backward per call (only the order of the sums inside a row differs);
+    more calls than HIPAD_DAF_MAX_CALLS are worked off in several passes."""
+    feat, ss, st, calls = _multi_calls(1, [(7, 13), (3, 40)] * 35)     # 70 calls > 64
+    assert len(calls) > lib.DAF_MAX_CALLS
+    d_ss, d_st, d_feat = torch.from_numpy(ss).cuda(), torch.from_numpy(st).cuda(), feat.cuda()
+    dc = [tuple(t.cuda() for t in c) for c in calls]
+    one = torch.zeros_like(d_feat)
+    for loc, w, gout in dc:
+        lib.daf_backward(d_feat, d_ss, d_st, loc, w, gout, one, None, None)
+    many = torch.zeros_like(d_feat)
+    lib.daf_backward_feat_multi(dc, many, d_ss, d_st)
+    assert rel_err(many, one.cpu().numpy()) < 1e-5
+
+
+def test_feat_multi_through_the_autograd_sink(lib, monkeypatch):
+    """shared_feature_grad + deferred feature gradient (the training step's path) == per-call pipelines."""
+    from projects.mmdet3d_plugin.ops import deformable_aggregation as DA
+    from projects.mmdet3d_plugin.ops import deformable_aggregation_function as DAF, shared_feature_grad
+    feat, ss, st, calls = _multi_calls(2, [(37, 13), (5, 300), (9, 90), (1, 13)])
+    d_ss, d_st = torch.from_numpy(ss).cuda().long(), torch.from_numpy(st).cuda().long()
+    grads = {}
+    for defer in (True, False):
+        monkeypatch.setattr(DA, "DEFER_FEAT", defer)
+        f = feat.cuda().to(torch.bfloat16).requires_grad_(True)      # the encoder's rows
+        shared = shared_feature_grad(f)
+        leaves, total = [], 0.0
+        for loc, w, gout in calls:
+            l, ww = loc.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+            leaves += [l, ww]
+            total = total + (DAF(shared, d_ss, d_st, l, ww) * gout.cuda()).sum()
+        total.backward()
+        grads[defer] = [f.grad.float()] + [t.grad for t in leaves]
+    assert rel_err(grads[True][0], grads[False][0].cpu().numpy()) < 1e-2      # bf16 leaf gradient: one rounding apart
+    for a, b in zip(grads[True][1:], grads[False][1:]):
+        assert torch.equal(a, b)                                             # grad_loc / grad_w: the same kernel

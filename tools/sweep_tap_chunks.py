@@ -1,0 +1,24 @@
+"""Frame feature-gradient pass (hipad_daf_backward_feat_multi over the 24 calls of a stage-2 frame) against the work
+split of its two tap passes (hipad_daf_set_tap_chunks).  GPU box.
+
+    python tools/sweep_tap_chunks.py [chunks ...]
+"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import hipad_amd  # noqa
+import torch
+import bench
+
+daf = bench.DafStage2(torch.device("cuda", 0), seed=0)
+lib = daf.lib.load()
+for nch in [int(v) for v in sys.argv[1:]] or [0, 2, 4, 8, 16, 24, 32, 48, 64]:
+    lib.hipad_daf_set_tap_chunks(nch)
+    daf.bwd_feat_frame()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        daf.bwd_feat_frame()
+    e1.record(); e1.synchronize()
+    print("chunks %3d (0 = auto): %.1f us per frame pass" % (nch, e0.elapsed_time(e1) / 20 * 1e3), flush=True)
+lib.hipad_daf_set_tap_chunks(0)
