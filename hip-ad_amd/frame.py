@@ -192,12 +192,8 @@ class TrainStep:
             losses = det.head.loss(self._outs, data)
         finally:
             count_exchange.begin("direct")
-        if self._depths is not None and "gt_depth" in data:
-            losses["loss_dense_depth"] = det.depth_branch.loss(self._depths, data["gt_depth"])
-        loss = None
-        for v in losses.values():
-            loss = v if loss is None else loss + v
-        return loss
+        return _sum_losses(losses, det.depth_branch.loss(self._depths, data["gt_depth"])
+                           if (self._depths is not None and "gt_depth" in data) else None)
 
     def part_loss_backward(self, whole=False):
         """Losses (normalised by the exchanged counts) + the backward down to the pyramid levels: every gradient of
@@ -543,8 +539,18 @@ def frame_losses(det, img, data):
         outs = det.head(img, feature_maps, data)
     losses = det.head.loss(outs, data)
     if depths is not None and "gt_depth" in data:
-        losses["loss_dense_depth"] = det.depth_branch.loss(depths, data["gt_depth"])
+        losses["loss_dense_depth"] = det.depth_branch.loss(depths, data["gt_depth"])   # (LossDict.total stays the decoder's)
     return losses
+
+
+def _sum_losses(losses, depth=None):
+    """Sum of the loss terms; a producer that already holds the sum of its terms (criterion.LossDict.total) saves the
+    chain of scalar additions."""
+    total = getattr(losses, "total", None)
+    if total is None:
+        for v in losses.values():
+            total = v if total is None else total + v
+    return total if depth is None else total + depth
 
 
 def _frame_loss(det, img, data):
@@ -553,10 +559,8 @@ def _frame_loss(det, img, data):
         outs = det.head(img, feature_maps, data)
         return surrogate_objective(outs, depths)
     losses = frame_losses(det, img, data)
-    total = None
-    for v in losses.values():
-        total = v if total is None else total + v
-    return total
+    depth = losses.pop("loss_dense_depth", None)
+    return _sum_losses(losses, depth)
 
 
 OBJECTIVE = "losses"  # "surrogate": mean square of every head output (debugging aid; skips target assignment)

@@ -46,6 +46,13 @@ SIGNATURES = {
     "hipad_layernorm_backward": (c_int, [c_void_p] * 8 + [c_int, c_int, c_void_p]),
     "hipad_linear_assignment": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
     "hipad_focal_loss_forward": (c_int, [c_void_p] * 6 + [ctypes.c_longlong, c_int, c_int, ctypes.c_float, ctypes.c_float, c_void_p]),
+    "hipad_loss_det_assign": (c_int, [c_void_p] * 11 + [c_int] * 7 + [c_void_p]),
+    "hipad_loss_det": (c_int, [c_void_p] * 13 + [c_int] * 8 + [c_void_p]),
+    "hipad_loss_map_assign": (c_int, [c_void_p] * 13 + [c_int] * 7 + [c_void_p]),
+    "hipad_loss_map": (c_int, [c_void_p] * 11 + [c_int] * 7 + [c_void_p]),
+    "hipad_loss_motion": (c_int, [c_void_p] * 7 + [c_int] + [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
+    "hipad_loss_plan": (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_void_p]),
+    "hipad_loss_scale": (c_int, [c_void_p] * 5 + [c_int, c_void_p]),
     "hipad_adamw_workspace": (c_size_t, []),
     "hipad_adamw_step": (c_int, [c_void_p] * 4 + [ctypes.c_longlong] * 2 + [ctypes.c_float] * 7
                          + [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p]),

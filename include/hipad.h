@@ -349,6 +349,126 @@ int hipad_focal_loss_forward(float *loss_per_layer, float *grad_logits, const fl
                              int layers, float alpha, float gamma, hipad_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * The decoder's training objective in a handful of launches (hip-ad_amd/csrc/lossprog.hip).
+ * Replaces: SparseOneDecoder.loss and its per-task pieces (models/sparse_onedecoder.py:1094-1579): samplers
+ *           det/target.py:66-162, map/target.py:38-62 + 105-160 (+ map/match_cost.py:8-106), motion/target.py:5-35 + 71-99,
+ *           plan/target.py:7-37 + 80-162; loss modules det/losses.py:11-93, map/loss.py:10-120 and mmdet 2.28.2's
+ *           FocalLoss / L1Loss / CrossEntropyLoss(use_sigmoid) / GaussianFocalLoss / FocalLossCost.
+ * All decoder layers at once: a prediction tensor is given as a table of per-layer DEVICE pointers (hipad_layer_ptrs,
+ * entry l = the head's output of layer l, [bs, rows, width] contiguous f32); ground truth is padded to G items per
+ * sample with a per-sample count (int32).  Every "grad_*" output is [layers, bs, rows, width] f32 and receives
+ * d(sum of the task's loss terms) / d(prediction) -- every element is written; `terms` outputs are [n_terms][layers] f32
+ * and are ACCUMULATED into (caller zero-fills once per step).  Loss term = sum over rows / (max(num_pos[l], 1) + eps)
+ * or the plain mean, times the loss weight, exactly as mmdet's weight_reduce_loss does it.
+ * The *_assign entries run cost matrix -> hipad_linear_assignment -> inverse map:
+ *   matched [layers*bs, P] i32 = ground-truth item of a prediction or -1;
+ *   count_out [2][layers] f32: [0] matched predictions whose target row is not all zero (the task's num_pos before the
+ *   cross-rank mean), [1] all assigned items (the motion head's num_pos).
+ * Scratch (cost, perm, n_rows, index) is caller-owned: cost [layers*bs, G, P] f32, perm same shape u8, n_rows
+ * [layers*bs] i32, index [layers*bs, G] i32 (prediction of each ground-truth item, -1 for padding).
+ * ---------------------------------------------------------------------------------- */
+#define HIPAD_LOSS_MAX_LAYERS 8
+#define HIPAD_LOSS_MAX_CLSWISE 4
+#define HIPAD_LOSS_MAX_GROUPS 16
+#define HIPAD_LOSS_MAX_INTERVALS 4
+#define HIPAD_LOSS_MAX_BUCKETS 8
+
+typedef struct hipad_layer_ptrs {
+  const float *p[HIPAD_LOSS_MAX_LAYERS];
+} hipad_layer_ptrs;
+
+typedef struct hipad_det_loss_cfg {
+  /* SparseBox3DTarget (det/target.py:66-162): cost = cls_weight * focal cost + box_weight * sum |box - target| * w * reg_w */
+  float cost_alpha, cost_gamma, cost_eps, cost_cls_weight, cost_box_weight;
+  float cost_reg_weights[10];
+  int num_cls_wise;                                   /* class-wise replacement of the NaN-aware weight row */
+  int cls_wise_label[HIPAD_LOSS_MAX_CLSWISE];
+  float cls_wise_weights[HIPAD_LOSS_MAX_CLSWISE][10];
+  /* losses: FocalLoss (w_cls) on all rows; L1 (w_box, per-dimension loss_reg_weights), centerness BCE (w_cns) and
+   * yawness Gaussian focal (w_yns, gauss_alpha) on matched rows whose best class score passes cls_threshold (<= 0: off) */
+  float focal_alpha, focal_gamma, w_cls, w_box, w_cns, w_yns, gauss_alpha, cls_threshold;
+  float loss_reg_weights[10];
+  int cns_index, yns_index;                           /* columns of the quality head */
+} hipad_det_loss_cfg;
+
+typedef struct hipad_map_loss_cfg {
+  /* roi normalisation (map/target.py:64-76): (v - origin) / norm per coordinate */
+  float origin_x, origin_y, norm_x, norm_y;
+  /* MapQueriesCost: FocalLossCost (alpha 0.25, gamma 2) * cost_cls_weight + LinesL1Cost(beta, permute) * cost_reg_weight */
+  float cost_cls_weight, cost_reg_weight, cost_beta;
+  float focal_alpha, focal_gamma, w_cls, w_line, loss_beta, cls_threshold;
+  float reg_weights[40];
+} hipad_map_loss_cfg;
+
+typedef struct hipad_motion_loss_cfg {
+  float focal_alpha, focal_gamma, w_cls, w_reg;
+} hipad_motion_loss_cfg;
+
+typedef struct hipad_plan_loss_cfg {
+  /* anchor group g: kind 0 = temp, 1 = spat (aligned to the reference group's winning mode), 2 = speed bucket;
+   * gt_traj[g] [bs, T, 2], gt_mask[g] [bs, T] = the group's ground truth (speed groups: their interval's) */
+  int kind[HIPAD_LOSS_MAX_GROUPS];
+  const float *gt_traj[HIPAD_LOSS_MAX_GROUPS];
+  const float *gt_mask[HIPAD_LOSS_MAX_GROUPS];
+  int ref_group;
+  int num_intervals;                                  /* speed intervals; interval i = interval_size[i] bucket groups */
+  int interval_size[HIPAD_LOSS_MAX_INTERVALS];
+  int interval_group[HIPAD_LOSS_MAX_INTERVALS][HIPAD_LOSS_MAX_BUCKETS];
+  float bucket_lo[HIPAD_LOSS_MAX_INTERVALS][HIPAD_LOSS_MAX_BUCKETS], bucket_hi[HIPAD_LOSS_MAX_INTERVALS][HIPAD_LOSS_MAX_BUCKETS];
+  const float *speed_traj, *speed_mask;               /* trajectory the ground-truth average speed is taken from */
+  float speed_interval;                               /* seconds between its way-points */
+  float focal_alpha, focal_gamma, w_cls, w_reg;
+  const float *ego_status, *ego_status_mask;          /* [bs, S] (S = 0: no ego-status term) */
+  float w_status;
+} hipad_plan_loss_cfg;
+
+int hipad_loss_det_assign(float *cost, int *n_rows, int *index, int *matched, float *count_out, const hipad_layer_ptrs *cls,
+                          const hipad_layer_ptrs *box, const float *gt_boxes, const long long *labels, const int *count,
+                          const hipad_det_loss_cfg *cfg, int layers, int bs, int P, int C, int D, int G, int gt_dim,
+                          hipad_stream_t stream);
+/* terms [4][layers]: class, box, centerness, yawness.  quality / grad_quality may be NULL with Q = 0.
+ * grad_box_cns [layers, bs, P, 3]: the centerness term's gradient into the box centre (its target exp(-|centre error|)
+ * is not detached in the reference, det/losses.py:55-60), kept apart from grad_box so that hipad_loss_scale can weight
+ * the two terms separately. */
+int hipad_loss_det(float *terms, float *grad_cls, float *grad_box, float *grad_box_cns, float *grad_quality,
+                   const hipad_layer_ptrs *cls, const hipad_layer_ptrs *box, const hipad_layer_ptrs *quality, const int *matched, const float *num_pos,
+                   const float *gt_boxes, const long long *labels, const hipad_det_loss_cfg *cfg, int layers, int bs, int P,
+                   int C, int D, int Q, int G, int gt_dim, hipad_stream_t stream);
+/* gt_pts [bs, G, num_permute, 40]; order [layers*bs, G] i32 (out) = point order of each matched ground-truth line */
+int hipad_loss_map_assign(float *cost, unsigned char *perm, int *n_rows, int *index, int *matched, int *order,
+                          float *count_out, const hipad_layer_ptrs *cls, const hipad_layer_ptrs *pts, const float *gt_pts,
+                          const long long *labels, const int *count, const hipad_map_loss_cfg *cfg, int layers, int bs, int P,
+                          int C, int pts_dim, int G, int num_permute, hipad_stream_t stream);
+/* terms [2][layers]: class, line */
+int hipad_loss_map(float *terms, float *grad_cls, float *grad_pts, const hipad_layer_ptrs *cls, const hipad_layer_ptrs *pts,
+                   const int *matched, const int *order, const float *num_pos, const float *gt_pts, const long long *labels,
+                   const hipad_map_loss_cfg *cfg, int layers, int bs, int P, int C, int pts_dim, int G, int num_permute,
+                   hipad_stream_t stream);
+/* cls [bs, A, M], reg [bs, A, M, T, 2] per layer; det_matched = the box head's `matched` (its LAST layer serves every
+ * layer, sparse_onedecoder.py:1287); num_pos[l * num_pos_stride]; trajs [bs, G, T, 2], masks [bs, G, T].
+ * terms [2][layers]: class, regression */
+int hipad_loss_motion(float *terms, float *grad_cls, float *grad_reg, const hipad_layer_ptrs *cls, const hipad_layer_ptrs *reg,
+                      const int *det_matched, const float *num_pos, int num_pos_stride, const float *trajs, const float *masks,
+                      const hipad_motion_loss_cfg *cfg, int layers, int bs, int A, int M, int T, int G, hipad_stream_t stream);
+/* cls [bs, num_groups * M], reg [bs, num_groups * M, T, 2] (way-point OFFSETS), status [bs, S] per layer (single driving
+ * command).  terms [7][layers]: temp cls, temp reg, spat cls, spat reg, speed cls, speed reg, ego status */
+int hipad_loss_plan(float *terms, float *grad_cls, float *grad_reg, float *grad_status, const hipad_layer_ptrs *cls,
+                    const hipad_layer_ptrs *reg, const hipad_layer_ptrs *status, const hipad_plan_loss_cfg *cfg, int layers,
+                    int bs, int num_groups, int M, int T, int S, hipad_stream_t stream);
+
+/* Backward of the objective: out[segment] = grads[segment] * g_terms[term of the element's column] (one launch for all
+ * segments; out may alias grads).  A segment is a [count / width, width] gradient tensor at `offset` floats into `grads`; term_table (device,
+ * int8) maps column -> term at table_offset; extra_offset >= 0 adds grads[extra_offset + row * extra_cols + col] *
+ * g_terms[extra_term] to the first extra_cols columns.  `segments` is a HOST array. */
+#define HIPAD_LOSS_MAX_SEGMENTS 16
+typedef struct hipad_loss_segment {
+  long long offset, count, extra_offset;
+  int width, table_offset, extra_cols, extra_term;
+} hipad_loss_segment;
+int hipad_loss_scale(float *out, const float *grads, const float *g_terms, const signed char *term_table,
+                     const hipad_loss_segment *segments, int num_segments, hipad_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Gradient clipping + AdamW over flat buffers (hip-ad_amd/csrc/optim.hip).
  * Replaces: the per-tensor optimiser step of the reference's training loop: mmcv OptimizerHook
  *           grad_clip (max_norm 25) + torch.optim.AdamW with the backbone at lr x0.5

@@ -427,6 +427,15 @@ def _tile(t, layers):
 import os as _os
 
 PLAN_LOSS_BATCHED = _os.environ.get("HIPAD_PLAN_LOSS_BATCHED", "1") == "1"   # 0: the group-by-group form
+FUSED_LOSS = _os.environ.get("HIPAD_FUSED_LOSS", "1") == "1"                 # 0: the torch-op formulation below on the GPU too
+
+
+class LossDict(dict):
+    """The loss terms by name, as the reference returns them, plus ``total`` = their sum when the producer already has it
+    (the fused objective: one reduction of its term vector instead of a chain of scalar additions)."""
+
+    total = None
+
 
 
 class DecoderLoss:
@@ -436,12 +445,79 @@ class DecoderLoss:
     truth is tiled, every op (costs, the Hungarian kernel, scatters, loss formulas) runs once for the six layers,
     and only the final reductions are per layer (each layer has its own ``num_pos``)."""
 
+    # ---- the objective through the fused loss kernels (hipad_amd/lossprog.py) ---------------------------------------
+    def _fused_objective(self, outs, gt):
+        """The FusedObjective of this decoder when this call can go through it: CUDA fp32 predictions, a configuration
+        the kernels cover, discrete choices not being recorded / replayed by a test (those hooks live in the torch-op
+        formulation), ground-truth padding within the kernels' tables."""
+        if not FUSED_LOSS:
+            return None
+        from hipad_amd import compat as _compat
+        if _compat.discrete_choice[0] is not _compat._identity_choice:
+            return None
+        probe = next((t for o in outs[:5] for v in o.values() if isinstance(v, list) for t in v if isinstance(t, torch.Tensor)), None)
+        if probe is None or not probe.is_cuda:
+            return None
+        fo = self.__dict__.get("_fused_obj")
+        if fo is None:
+            from hipad_amd import lossprog
+            fo = lossprog.FusedObjective(self).bind(self) if lossprog.FusedObjective.supports(self) else False
+            self.__dict__["_fused_obj"] = fo
+        if not fo:
+            return None
+        for o in outs[:5]:
+            for v in o.values():
+                if isinstance(v, list) and any(isinstance(t, torch.Tensor) and t.dtype != torch.float32 for t in v):
+                    return None
+        layers = len(outs[0]["classification"]) if "det" in self.task_select else len(outs[3]["classification"])
+        if layers > 8 or ("det" in gt and gt["det"]["boxes"].shape[1] > 64) or \
+                ("map" in gt and (gt["map"]["pts"].shape[1] > 64 or gt["map"]["pts"].shape[2] > 255 or gt["map"]["pts"].shape[-1] != 40)):
+            return None
+        return fo
+
+    def _fused_counts(self, assigned):
+        """The positive counts of the matched tasks through ``reduce_mean``, in the order of the torch-op formulation."""
+        num_pos = {}
+        if "det" in self.task_select:
+            num_pos["det"] = reduce_mean(assigned["det"]["counts"][0])
+        if "map" in self.task_select:
+            num_pos["map"] = reduce_mean(assigned["map"]["counts"][0])
+        if "motion" in self.task_select:
+            raw = assigned["det"]["counts"][1]
+            num_pos["motion"] = reduce_mean(raw[-1:].expand(raw.shape[0]))   # the LAST layer's matching serves every layer
+        return num_pos
+
+    def _loss_fused(self, fo, outs, data, gt):
+        from hipad_amd import lossprog
+        assigned = self.__dict__.pop("_assigned", None) or fo.assign(outs[0], outs[1], gt)
+        if "det" in assigned:
+            self.det_sampler.indices = assigned["det"]["index"]
+        vec = fo.losses(outs[:5], data, gt, assigned, self._fused_counts(assigned))
+        active = {"det": lossprog.TERMS[0:4], "map": lossprog.TERMS[4:6], "motion": lossprog.TERMS[6:8],
+                  "plan": lossprog.TERMS[8:14], "ego": lossprog.TERMS[14:15]}
+        kinds = {t[0] for t in getattr(self, "plan_anchor_types", [])}
+        out = LossDict()
+        for task in ("det", "map", "ego", "motion", "plan"):
+            if task in self.task_select:
+                for name in active[task]:
+                    if task == "plan" and name.split("_")[2] not in kinds:
+                        continue
+                    out[name] = vec[lossprog.TERMS.index(name)]
+        out.total = vec.sum()
+        return out
+
     def positive_counts(self, det_output, map_output, ego_output, plan_output, motion_output, scenes_output, data):
         """Phase 1 of a data-parallel step (hipad_amd.compat.CountExchange): the target assignment of the matched tasks
         and their positive counts, which ``reduce_mean`` hands to the exchange buffer -- in the order ``loss`` asks for
         them again.  The assignments are kept and reused by the following ``loss`` call (not recomputed)."""
         gt = data.get("gt_padded") or pad_ground_truth(data)
         self._sampled = {}
+        fo = self._fused_objective((det_output, map_output, ego_output, plan_output, motion_output), gt)
+        if fo is not None:
+            with torch.no_grad():
+                self.__dict__["_assigned"] = fo.assign(det_output, map_output, gt)
+                self._fused_counts(self.__dict__["_assigned"])
+            return
         with torch.no_grad():
             if "det" in self.task_select:
                 self._sampled["det_"] = self._sample_targets(det_output, gt["det"], self.det_sampler, self.det_reg_weights)
@@ -466,6 +542,11 @@ class DecoderLoss:
 
     def loss(self, det_output, map_output, ego_output, plan_output, motion_output, scenes_output, data):
         gt = data.get("gt_padded") or pad_ground_truth(data)
+        outs = (det_output, map_output, ego_output, plan_output, motion_output)
+        fo = self._fused_objective(outs, gt)
+        if fo is not None:
+            return self._loss_fused(fo, outs, data, gt)
+        self.__dict__.pop("_assigned", None)
         losses = {}
         if "det" in self.task_select:
             losses.update(self.loss_det(det_output, gt["det"]))
