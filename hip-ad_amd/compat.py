@@ -290,6 +290,10 @@ def _identity_choice(tag, choice):
 # through ``discrete_choice[0](tag, index_tensor)``.  Identity in the product; parity tests swap in a recorder / replayer
 # so that two numerically different runs are compared on the same choices instead of on near-ties that fell the other way.
 discrete_choice = [_identity_choice]
+# "all": the hook sees every tag, and code paths that make such choices INSIDE a fused kernel (the fused training objective:
+# assignment, line order, winning mode, class gate) step aside for the torch-op formulation while a hook is installed.
+# "decoder": the hook only cares about the decoder's own choices ("topk", "motion_class"); the fused objective stays on.
+discrete_scope = ["all"]
 
 
 def discrete(tag, choice):

@@ -22,9 +22,29 @@
 namespace hipad {
 
 // The reductions need many workgroups in flight to reach HBM speed, but every workgroup ends with one atomic per channel:
-// same-address fp32 atomics retire at ~20 ns each, so the per-channel sums are kept in kReplicas copies (workgroup b adds to
+// same-address atomics retire at ~20 ns each, so the per-channel sums are kept in kReplicas copies (workgroup b adds to
 // copy b % kReplicas) and the consumers add the copies up.
+//
+// The sums are accumulated as 64-bit FIXED-POINT integers: integer addition is associative, so the result does not
+// depend on the order in which the workgroups' atomics arrive and the statistics -- hence the whole encoder forward and
+// every activation derived from it -- are bitwise reproducible from run to run.  With fp32 atomics the sums moved in the
+// last bit, the bf16 activations of the following layers flipped roundings here and there, and two runs of the same
+// frame ended 4e-3 apart in the pyramid (relative L2; tools/diag_forward_determinism.py), which the random-init decoder
+// amplifies to tens of percent in the gradient.  A workgroup's own partial sum is a fixed-order fp32 sum as before; its
+// conversion (round to nearest at 2^-24 resp. 2^-40) costs 1e-7 relative on sums of magnitude >= 1, fp32 level.
 constexpr int kReplicas = 4;
+constexpr double kFwdScale = 16777216.0;              // 2^24: range 5e11 (sum of squares of 1e6 rows of |x| ~ 700)
+constexpr double kBwdScale = 1099511627776.0;         // 2^40: range 8e6, resolution 9e-13 (gradient sums are small)
+
+__device__ __forceinline__ long long to_fixed(float v, double scale) {
+  const double d = (double)v * scale;
+  if (!(d == d)) return 0;                            // NaN input: the statistics are garbage either way; keep the sum finite
+  return d >= 9.0e18 ? 9000000000000000000ll : (d <= -9.0e18 ? -9000000000000000000ll : __double2ll_rn(d));
+}
+__device__ __forceinline__ float from_fixed(long long v, double scale) { return (float)((double)v / scale); }
+__device__ __forceinline__ void add_fixed(long long *dst, float v, double scale) {
+  atomicAdd(reinterpret_cast<unsigned long long *>(dst), (unsigned long long)to_fixed(v, scale));
+}
 constexpr int kUnroll = 4;   // rows per thread in flight
 
 __device__ __forceinline__ void unpack8(const uint4 &u, float *f) {
@@ -56,8 +76,8 @@ __device__ __forceinline__ uint4 pack8(const float *f) {
 // channel and quantity.  All 256 threads take part: the 2C outputs are dealt over the threads (two threads per output
 // when 2C < 256), so a thread reads at most 16 LDS words -- with only the C / 8 threads of one row doing the sums (first
 // version) a 64-channel layer spent 15 us here.
-__device__ __forceinline__ void combine_and_add(float *__restrict__ gsum, const float *a, const float *b, int tpr, int C,
-                                                float (*sh)[17], float *sh2) {
+__device__ __forceinline__ void combine_and_add(long long *__restrict__ gsum, double scale, const float *a, const float *b,
+                                                int tpr, int C, float (*sh)[17], float *sh2) {
   const int tid = threadIdx.x;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -71,7 +91,7 @@ __device__ __forceinline__ void combine_and_add(float *__restrict__ gsum, const 
       const int q = o / C, c = o - q * C, lc = c >> 3, k = (c & 7) + 8 * q;
       float acc = 0.f;
       for (int lr = 0; lr < rpi; ++lr) acc += sh[lr * tpr + lc][k];
-      atomicAdd(gsum + o, acc);
+      add_fixed(gsum + o, acc, scale);
     }
   } else {                       // 2C = 128: two threads per output, each over half of the rows in flight
     const int o = tid % outs, half = tid / outs, parts = 256 / outs;
@@ -83,12 +103,12 @@ __device__ __forceinline__ void combine_and_add(float *__restrict__ gsum, const 
     __syncthreads();
     if (tid < outs) {
       for (int p = 1; p < parts; ++p) acc += sh2[tid + p * outs];
-      atomicAdd(gsum + o, acc);
+      add_fixed(gsum + o, acc, scale);
     }
   }
 }
 
-__global__ __launch_bounds__(256) void bn_stats_kernel(float *__restrict__ sums, const uint4 *__restrict__ x, long rows, int C,
+__global__ __launch_bounds__(256) void bn_stats_kernel(long long *__restrict__ sums, const uint4 *__restrict__ x, long rows, int C,
                                                        long rows_per_block) {
   __shared__ float sh[256][17];
   __shared__ float sh2[256];
@@ -121,11 +141,11 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(float *__restrict__ sums,
       }
     }
   }
-  combine_and_add(sums + (blockIdx.x % kReplicas) * 2 * C, s, ss, tpr, C, sh, sh2);
+  combine_and_add(sums + (blockIdx.x % kReplicas) * 2 * C, kFwdScale, s, ss, tpr, C, sh, sh2);
 }
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(uint4 *__restrict__ y, const uint4 *__restrict__ x,
-                                                       const uint4 *__restrict__ residual, const float *__restrict__ sums,
+                                                       const uint4 *__restrict__ residual, const long long *__restrict__ sums,
                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
                                                        float *__restrict__ running_mean, float *__restrict__ running_var,
                                                        float *__restrict__ save /* [2C]: mean, rstd */, long rows, int C,
@@ -139,12 +159,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(uint4 *__restrict__ y, co
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int c = lc * 8 + k;
-    s1[k] = s2[k] = 0.f;
+    long long q1 = 0, q2 = 0;                      // the replicas are summed as integers: order-free too
 #pragma unroll
     for (int rep = 0; rep < kReplicas; ++rep) {
-      s1[k] += sums[rep * 2 * C + c];
-      s2[k] += sums[rep * 2 * C + C + c];
+      q1 += sums[rep * 2 * C + c];
+      q2 += sums[rep * 2 * C + C + c];
     }
+    s1[k] = from_fixed(q1, kFwdScale);
+    s2[k] = from_fixed(q2, kFwdScale);
     gm[k] = gamma[c];
     bt[k] = beta[c];
   }
@@ -207,7 +229,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(uint4 *__restrict__ y, co
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(float *__restrict__ gsums, const uint4 *__restrict__ dy,
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(long long *__restrict__ gsums, const uint4 *__restrict__ dy,
                                                             const uint4 *__restrict__ y /* NULL: no ReLU gate */,
                                                             const uint4 *__restrict__ x, const float *__restrict__ save,
                                                             long rows, int C, long rows_per_block) {
@@ -256,14 +278,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(float *__restrict__ 
       }
     }
   }
-  combine_and_add(gsums + (blockIdx.x % kReplicas) * 2 * C, s, sx, tpr, C, sh, sh2);
+  combine_and_add(gsums + (blockIdx.x % kReplicas) * 2 * C, kBwdScale, s, sx, tpr, C, sh, sh2);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(uint4 *__restrict__ dx, uint4 *__restrict__ dres /* may be NULL */,
                                                            float *__restrict__ dgamma, float *__restrict__ dbeta,
                                                            const uint4 *__restrict__ dy, const uint4 *__restrict__ y,
                                                            const uint4 *__restrict__ x, const float *__restrict__ save,
-                                                           const float *__restrict__ gamma, const float *__restrict__ gsums,
+                                                           const float *__restrict__ gamma, const long long *__restrict__ gsums,
                                                            long rows, int C, long rows_per_block) {
   const int tpr = C >> 3, rpi = 256 / tpr;
   const int lc = threadIdx.x % tpr, lr = threadIdx.x / tpr;
@@ -274,12 +296,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(uint4 *__restrict__ d
     const int c = lc * 8 + k;
     mean[k] = save[c];
     rstd[k] = save[C + c];
-    sdy[k] = sdyx[k] = 0.f;
+    long long q1 = 0, q2 = 0;
 #pragma unroll
     for (int rep = 0; rep < kReplicas; ++rep) {
-      sdy[k] += gsums[rep * 2 * C + c];
-      sdyx[k] += gsums[rep * 2 * C + C + c];
+      q1 += gsums[rep * 2 * C + c];
+      q2 += gsums[rep * 2 * C + C + c];
     }
+    sdy[k] = from_fixed(q1, kBwdScale);
+    sdyx[k] = from_fixed(q2, kBwdScale);
     gr[k] = gamma[c];
   }
 #pragma unroll
@@ -371,9 +395,11 @@ int hipad_bn_forward(void *y, float *save, float *sums, const void *x, const voi
   unsigned blocks;
   long rpb;
   bn_grid((long)rows, channels, &blocks, &rpb);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks), dim3(256), 0, stream, sums, (const uint4 *)x, (long)rows, channels, rpb);
+  if ((uintptr_t)sums & 7) return HIPAD_EINVAL;
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks), dim3(256), 0, stream, (long long *)sums, (const uint4 *)x, (long)rows,
+                     channels, rpb);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, stream, (uint4 *)y, (const uint4 *)x,
-                     (const uint4 *)residual, sums, gamma, beta, running_mean, running_var, save, (long)rows, channels, eps,
+                     (const uint4 *)residual, (const long long *)sums, gamma, beta, running_mean, running_var, save, (long)rows, channels, eps,
                      momentum, relu ? 1 : 0, rpb);
   return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
 }
@@ -388,10 +414,12 @@ int hipad_bn_backward(void *dx, void *dres, float *dgamma, float *dbeta, float *
   unsigned blocks;
   long rpb;
   bn_grid((long)rows, channels, &blocks, &rpb);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks), dim3(256), 0, stream, gsums, (const uint4 *)dy, (const uint4 *)y,
-                     (const uint4 *)x, save, (long)rows, channels, rpb);
+  if ((uintptr_t)gsums & 7) return HIPAD_EINVAL;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (long long *)gsums, (const uint4 *)dy,
+                     (const uint4 *)y, (const uint4 *)x, save, (long)rows, channels, rpb);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, stream, (uint4 *)dx, (uint4 *)dres, dgamma, dbeta,
-                     (const uint4 *)dy, (const uint4 *)y, (const uint4 *)x, save, gamma, gsums, (long)rows, channels, rpb);
+                     (const uint4 *)dy, (const uint4 *)y, (const uint4 *)x, save, gamma, (const long long *)gsums, (long)rows,
+                     channels, rpb);
   return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
 }
 

@@ -156,7 +156,7 @@ class _BatchNormAct(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, running_mean, running_var, eps, momentum, relu):
         c = x.shape[1]
-        n = _lib.BN_REPLICAS * 2 * c
+        n = _lib.BN_REPLICAS * 2 * c * _lib.BN_SUM_FLOATS
         sums = BN_ARENA.take(n, x.device)
         ctx.gsums = BN_ARENA.take(n, x.device) if any(ctx.needs_input_grad[:4]) else None
         y, save = _lib.bn_forward(x, residual, weight.detach(), bias.detach(), running_mean, running_var, sums, eps, momentum, relu)
@@ -185,7 +185,7 @@ class _BatchNormAct(Function):
                 targets.append(None)
         gsums, ctx.gsums = ctx.gsums, None          # the reserved slice is zero only once (retain_graph: fresh zeros after)
         if gsums is None:
-            gsums = torch.zeros(_lib.BN_REPLICAS * 2 * x.shape[1], dtype=torch.float32, device=x.device)
+            gsums = torch.zeros(_lib.BN_REPLICAS * 2 * x.shape[1] * _lib.BN_SUM_FLOATS, dtype=torch.float32, device=x.device)
         dx, dres = _lib.bn_backward(dy, y, x, save, weight.detach(), gsums, targets[0], targets[1],
                                     ctx.has_res and ctx.needs_input_grad[3])
         return dx if ctx.needs_input_grad[0] else None, rets[0], rets[1], dres, None, None, None, None, None

@@ -601,6 +601,7 @@ def focal_loss_forward(logits, target, weight, avg_factor, layers, alpha, gamma)
 
 
 BN_REPLICAS = 4
+BN_SUM_FLOATS = 2       # a partial sum is one 64-bit fixed-point word = two float slots of the scratch buffer
 
 
 def bn_supported(rows, channels):
@@ -608,7 +609,8 @@ def bn_supported(rows, channels):
 
 
 def bn_forward(x, residual, gamma, beta, running_mean, running_var, sums, eps, momentum, relu):
-    """x (N, C, H, W) bf16 channels-last -> (y like x, save (2C,) fp32).  ``sums``: zeroed fp32 (BN_REPLICAS * 2C,)."""
+    """x (N, C, H, W) bf16 channels-last -> (y like x, save (2C,) fp32).  ``sums``: zeroed scratch of BN_REPLICAS * 2C * BN_SUM_FLOATS
+    floats (64-bit fixed-point partial sums, see include/hipad.h)."""
     lib = load()
     n, c, h, w = x.shape
     rows = n * h * w

@@ -662,7 +662,10 @@ int hipad_image_finish(float *out, const long long *out_strides, const unsigned 
  * the library's 3 + 3 BatchNorm launches plus the ReLU (and add) launches by two launches each way.
  *   x, y, residual, dy, dx, dres: (rows, channels) row-major bf16 = NHWC with rows = N*H*W, 16-byte aligned.
  *   channels in {64, 128, 256, 512, 1024, 2048} (hipad_bn_supported).
- *   sums / gsums: HIPAD_BN_REPLICAS x 2 x channels floats, ZERO on entry (partial-sum copies; consumed by the same call).
+ *   sums / gsums: HIPAD_BN_REPLICAS x 2 x channels 64-bit words (8-byte aligned; declared float* for the allocator's sake:
+ *                 2 floats per word), ZERO on entry.  Partial-sum copies in 64-bit fixed point -- integer accumulation is
+ *                 order-independent, so the statistics (and everything computed from them) are bitwise reproducible
+ *                 although the workgroups' atomics arrive in any order; consumed by the same call.
  *   save: 2 x channels floats (batch mean, 1 / sqrt(var + eps)) written by the forward for the backward.
  *   hipad_bn_forward:  y = relu?((x - mean) * rstd * gamma + beta (+ residual)); biased batch variance; when
  *                      running_mean / running_var are given they are updated in place with `momentum` (unbiased variance),

@@ -453,7 +453,7 @@ class DecoderLoss:
         if not FUSED_LOSS:
             return None
         from hipad_amd import compat as _compat
-        if _compat.discrete_choice[0] is not _compat._identity_choice:
+        if _compat.discrete_choice[0] is not _compat._identity_choice and _compat.discrete_scope[0] != "decoder":
             return None
         probe = next((t for o in outs[:5] for v in o.values() if isinstance(v, list) for t in v if isinstance(t, torch.Tensor)), None)
         if probe is None or not probe.is_cuda:

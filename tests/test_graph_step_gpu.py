@@ -47,6 +47,109 @@ def run(mode, steps):
     return trace
 
 
+DECODER_TAGS = ("topk", "motion_class")
+
+
+class Choices:
+    """Recorder / replayer of the decoder's discrete choices (hipad_amd.compat.discrete_choice) frame by frame.  Replayed
+    choices are served from STATIC device buffers filled before the frame starts, so a captured step reads them too."""
+
+    def __init__(self, recorded=None, tags=DECODER_TAGS):
+        self.frames = [] if recorded is None else recorded
+        self.replay = recorded is not None
+        self.tags = tags                     # None: every tag (the loss path's assignment / order / mode / gate choices too)
+        self.bufs, self.i, self.k = {}, 0, -1
+
+    def begin_frame(self, k):
+        self.k, self.i = k, 0
+        if not self.replay:
+            while len(self.frames) <= k:
+                self.frames.append([])
+            self.frames[k] = []
+            return
+        for i, (tag, t) in enumerate(self.frames[k]):
+            key = (i, tag, tuple(t.shape))
+            if key not in self.bufs:
+                self.bufs[key] = torch.empty_like(t)
+            self.bufs[key].copy_(t)
+
+    def __call__(self, tag, choice):
+        if self.tags is not None and tag not in self.tags:
+            return choice
+        if not self.replay:
+            self.frames[self.k].append((tag, choice.clone()))
+            return choice
+        rtag, t = self.frames[self.k][self.i]
+        assert rtag == tag and t.shape == choice.shape, (self.k, self.i, rtag, tag)
+        buf = self.bufs[(self.i, tag, tuple(t.shape))]
+        self.i += 1
+        return buf
+
+
+def pinned_run(mode, steps, recorded, scope="all", first=5, encoder_dtype=None):
+    """Frames 5 .. steps-1 of the eager or the replayed step with the decoder's discrete choices recorded (``recorded`` None)
+    or replayed: per frame the loss, the pre-clip gradient norm and a copy of the flat gradient (+ the segment split)."""
+    from hipad_amd import compat as CR, functional as HF
+    from hipad_amd.frame import GraphedTrainStep, SyntheticFrames, TrainStep, build_detector
+    torch.manual_seed(5)
+    model, cfg = build_detector(stage=2, plan_queries=480, encoder_dtype=encoder_dtype)
+    model.train()
+    quiet(model)
+    model.head.onedecoder_head.with_instance_id = False    # as in the captured step (track ids: a top-k of their own)
+    cfg["optimizer"] = dict(cfg["optimizer"], lr=0.0, weight_decay=0.0)
+    frames = SyntheticFrames(seed=3)
+    # scope "all": every discrete choice incl. the target assignment is pinned (the objective then runs in its torch-op
+    # formulation, which hosts those hooks); "decoder": only the decoder's own choices, the fused objective stays on
+    choices = Choices(recorded, None if scope == "all" else DECODER_TAGS)
+    plain_next = frames.next
+
+    def next_frame():
+        choices.begin_frame(frames.step)
+        return plain_next()
+    frames.next = next_frame
+    identity, scope_before = CR.discrete_choice[0], CR.discrete_scope[0]
+    CR.discrete_choice[0], CR.discrete_scope[0] = choices, scope
+    names = {id(p): n for n, p in model.named_parameters()}
+    out = []
+    try:
+        if mode == "eager":
+            step = TrainStep(model, cfg)
+            for k in range(steps):
+                img, data = frames.next()
+                step.part_forward(img, data, keep_levels=True)
+                step.exchange_counts()
+                loss = step.part_loss_backward()
+                step.part_backward_encoder()
+                step.grads.check_views()
+                flat = step.grads.flat.clone()
+                step.update()
+                HF.advance_dropout_clock(img.device)
+                if k >= first:
+                    out.append(dict(loss=float(loss), norm=float(step.grad_norm), flat=flat, split=step.grads.split))
+        else:
+            g = GraphedTrainStep(model, cfg, frames)     # frames 0..4 (eager warm-up, capture, first replay)
+            for k in range(5, steps):
+                g._feed(*frames.next())
+                g.graph_f.replay()
+                flat = g.inner.grads.flat.clone()
+                g.graph_b.replay()
+                out.append(dict(loss=float(g.loss), norm=float(g.inner.grad_norm), flat=flat, split=g.inner.grads.split))
+    finally:
+        CR.discrete_choice[0], CR.discrete_scope[0] = identity, scope_before
+    grads = step.grads if mode == "eager" else g.inner.grads
+    layout = [(names[id(p)], off, p.numel()) for p, off in zip(grads.params, grads.offsets)]
+    for o in out:
+        o["layout"] = layout
+    return out, choices.frames
+
+
+def segment_distances(a, b):
+    """Relative L2 distance of the two flat gradients: (decoder + depth heads segment, FPN + backbone segment)."""
+    s = a["split"]
+    return tuple(float((a["flat"][lo:hi] - b["flat"][lo:hi]).norm() / a["flat"][lo:hi].norm().clamp_min(1e-30))
+                 for lo, hi in ((0, s), (s, a["flat"].numel())))
+
+
 def test_replayed_step_tracks_eager_step():
     warnings.filterwarnings("ignore")
     from hipad_amd import functional as HF
