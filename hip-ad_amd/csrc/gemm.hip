@@ -92,6 +92,24 @@ __device__ __forceinline__ void lstore_rowmajor(short (*T)[LDS_STRIDE], const fl
   }
 }
 
+// the same with the activation kept as a hi + lo bf16 PAIR (x = hi + lo + O(2^-17 x)): the MFMA then sees ~16 mantissa
+// bits of the activation and only the weight is rounded to bf16 -- as the MLP-chain kernels do (chain.hip)
+__device__ __forceinline__ float bf16_f(short h) { return (float)__builtin_bit_cast(__bf16, h); }
+template <int ROWS>
+__device__ __forceinline__ void lstore_rowmajor_hilo(short (*T)[LDS_STRIDE], short (*TL)[LDS_STRIDE],
+                                                     const float4 (&v)[ROWS / 4], int tid) {
+  const int kk = (tid & 31) * 8, rr = tid >> 5;
+#pragma unroll
+  for (int p = 0; p < ROWS / 8; ++p) {
+    const float4 a = v[2 * p], b = v[2 * p + 1];
+    const bf16x8 hi = pack8(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
+    *reinterpret_cast<bf16x8 *>(&T[rr + 8 * p][kk]) = hi;
+    *reinterpret_cast<bf16x8 *>(&TL[rr + 8 * p][kk]) =
+        pack8(a.x - bf16_f(hi[0]), a.y - bf16_f(hi[1]), a.z - bf16_f(hi[2]), a.w - bf16_f(hi[3]), b.x - bf16_f(hi[4]),
+              b.y - bf16_f(hi[5]), b.z - bf16_f(hi[6]), b.w - bf16_f(hi[7]));
+  }
+}
+
 // ---- operand chunk, reduction index STRIDED in memory: T[r][kk] = src[(k0 + kk) * ld + r0 + r]
 // thread -> blocks of 4 r x 8 kk (8 float4 loads along r, transposed in registers, 4 16-byte LDS stores)
 template <int ROWS, bool VEC>
@@ -133,12 +151,14 @@ __device__ __forceinline__ void lstore_trans(short (*T)[LDS_STRIDE], const float
 //   EPI 0: C = relu?(acc + bias[n])  stored;   EPI 1: atomicAdd(C, acc) + optional row sums of A_op
 //   grid = (ceil(N/32), ceil(M/64), splits over the reduction); k_per_split is a multiple of KC
 // One 64 x 32 output tile (tile coordinates bx, by, split bz) of the product; TA / TB: the workgroup's LDS.
-template <bool A_TRANS, bool B_TRANS, int EPI, bool VA, bool VB>
+template <bool A_TRANS, bool B_TRANS, int EPI, bool VA, bool VB, bool HILO = false>
 __device__ __forceinline__ void gemm_tile(short (*TA)[LDS_STRIDE], short (*TB)[LDS_STRIDE], float *__restrict__ C,
                                           const float *__restrict__ A, const float *__restrict__ A_gate,
                                           const float *__restrict__ B, const float *__restrict__ bias,
                                           float *__restrict__ rowsum_out, int M, int N, int K, int lda, int ldb, int ldc,
-                                          int relu, int k_per_split, int bx, int by, int bz) {
+                                          int relu, int k_per_split, int bx, int by, int bz,
+                                          short (*TAL)[LDS_STRIDE] = nullptr /* HILO: low halves of A_op */) {
+  static_assert(!HILO || !A_TRANS, "hi + lo activations: row-major A only");
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int l15 = lane & 15, quad = lane >> 4;
   const int m0 = by * BM, n0 = bx * BN;
@@ -165,7 +185,9 @@ __device__ __forceinline__ void gemm_tile(short (*TA)[LDS_STRIDE], short (*TB)[L
 
   fetch(kbeg);
   for (int k0 = kbeg; k0 < kend; k0 += KC) {
-    if (A_TRANS) lstore_trans<BM>(TA, ra, tid); else lstore_rowmajor<BM>(TA, ra, tid);
+    if (A_TRANS) lstore_trans<BM>(TA, ra, tid);
+    else if (HILO) lstore_rowmajor_hilo<BM>(TA, TAL, ra, tid);
+    else lstore_rowmajor<BM>(TA, ra, tid);
     if (B_TRANS) lstore_trans<BN>(TB, rb, tid); else lstore_rowmajor<BN>(TB, rb, tid);
     __syncthreads();
     if (k0 + KC < kend) fetch(k0 + KC);  // next chunk's loads fly during the MFMA phase
@@ -176,6 +198,11 @@ __device__ __forceinline__ void gemm_tile(short (*TA)[LDS_STRIDE], short (*TB)[L
       const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(&TB[16 + l15][32 * s + 8 * quad]);
       acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, acc[1], 0, 0, 0);
+      if (HILO) {
+        const bf16x8 al = *reinterpret_cast<const bf16x8 *>(&TAL[16 * wv + l15][32 * s + 8 * quad]);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, b1, acc[1], 0, 0, 0);
+      }
     }
     if (EPI == 1 && rowsum_out && bx == 0) {
       // sum over the chunk of A_op[row = tid/4][.]: each thread a quarter of the row, then 2 shuffles
@@ -225,6 +252,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(float *__restrict__ C, const 
   __shared__ short TB[BN][LDS_STRIDE];
   gemm_tile<A_TRANS, B_TRANS, EPI, VA, VB>(TA, TB, C, A, A_gate, B, bias, rowsum_out, M, N, K, lda, ldb, ldc, relu,
                                            k_per_split, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Forward Linear with hi + lo activations: Y = relu?(X W^T + b), X row-major.
+template <bool VA, bool VB>
+__global__ __launch_bounds__(256) void gemm_fwd_hilo_kernel(float *__restrict__ C, const float *__restrict__ A,
+                                                            const float *__restrict__ B, const float *__restrict__ bias, int M,
+                                                            int N, int K, int lda, int ldb, int ldc, int relu, int k_per_split) {
+  __shared__ short TA[BM][LDS_STRIDE];
+  __shared__ short TAL[BM][LDS_STRIDE];
+  __shared__ short TB[BN][LDS_STRIDE];
+  gemm_tile<false, false, 0, VA, VB, true>(TA, TB, C, A, nullptr, B, bias, nullptr, M, N, K, lda, ldb, ldc, relu, k_per_split,
+                                           blockIdx.x, blockIdx.y, blockIdx.z, TAL);
 }
 
 // Backward of a Linear in ONE launch: the first `dx_tiles` workgroups compute dX = (dY o gate) W (overwrite), the
@@ -498,9 +537,14 @@ int hipad_linear_forward(float *y, const float *x, const float *weight, const fl
   if (!y || !x || !weight) return HIPAD_EINVAL;
   const dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, 1);
   const int kall = (K + KC - 1) / KC * KC;
-  // C[m][n] = sum_k X[m][k] W[n][k]
-  HIPAD_GEMM(false, false, 0, vec_ok(x, K), vec_ok(weight, K), grid, (hipStream_t)stream, y, x,
-             (const float *)nullptr, weight, bias, (float *)nullptr, M, N, K, K, K, N, relu, kall);
+  // C[m][n] = sum_k X[m][k] W[n][k], activations as hi + lo bf16 pairs (only the weights are rounded to bf16)
+  const bool va = vec_ok(x, K), vb = vec_ok(weight, K);
+#define HIPAD_FWD_HILO(VA_, VB_)                                                                                      \
+  hipLaunchKernelGGL((gemm_fwd_hilo_kernel<VA_, VB_>), grid, dim3(256), 0, (hipStream_t)stream, y, x, weight, bias, M, N, \
+                     K, K, K, N, relu, kall)
+  if (va) { if (vb) HIPAD_FWD_HILO(true, true); else HIPAD_FWD_HILO(true, false); }
+  else { if (vb) HIPAD_FWD_HILO(false, true); else HIPAD_FWD_HILO(false, false); }
+#undef HIPAD_FWD_HILO
   return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
 }
 

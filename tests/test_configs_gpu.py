@@ -85,3 +85,56 @@ def test_config5_stage2_resnet101_1600x640_trains():
     dec = model.head.onedecoder_head
     assert dec.total_num_anchor == 1481
     assert all(np.isfinite(v) and abs(v) < 1e6 for pair in trace for v in pair), trace
+
+
+def test_config4_stage2_bs2():
+    """BASELINE.json config 4 (hipad_b2d_stage2, 2 frames per GPU): two finite training steps at bs = 2, and -- in eval
+    mode, stochastic layers off, cold instance banks -- every head output of the bs = 2 batch equals the outputs of the
+    same two frames run as bs = 1 passes (1e-3 of the tensor's largest magnitude: samples do not mix anywhere)."""
+    import copy
+    from hipad_amd.frame import SyntheticFrames, TrainStep, build_detector
+    warnings.filterwarnings("ignore")
+    torch.manual_seed(3)
+    model, cfg = build_detector(stage=2, plan_queries=480)
+    torch.backends.cudnn.benchmark = False
+    model.train()
+    frames = SyntheticFrames(bs=2, seed=1)
+    step = TrainStep(copy.deepcopy(model), cfg)
+    trace = []
+    for _ in range(2):
+        loss = step(*frames.next())
+        trace.append((float(loss), float(step.grad_norm)))
+    assert all(np.isfinite(v) and abs(v) < 1e6 for pair in trace for v in pair), trace
+
+    # sample independence with an fp32 encoder: MIOpen picks other solvers for 12 images than for 6, and in bf16 that
+    # alone moves the pyramid by 1e-3 (amplified x3 by the third decoder layer: 2.3e-3 measured on det class scores)
+    torch.manual_seed(3)
+    model, _ = build_detector(stage=2, plan_queries=480, encoder_dtype=torch.float32)
+    model.eval()
+    model.use_grid_mask = False
+    dec = model.head.onedecoder_head
+    dec.with_instance_id = False
+    img, data = SyntheticFrames(bs=2, seed=4).next()
+
+    def run(sl):
+        m = copy.deepcopy(model)       # cold banks for every pass
+        d = {k: (v[sl] if isinstance(v, torch.Tensor) and v.shape[:1] == img.shape[:1] else v) for k, v in data.items()}
+        d["img_metas"] = data["img_metas"][sl]
+        with torch.no_grad():
+            fm = m.extract_feat(img[sl], False, d)
+            return m.head(img[sl], fm, d)
+
+    both = run(slice(0, 2))
+    singles = [run(slice(b, b + 1)) for b in range(2)]
+    checked = 0
+    for ti, out in enumerate(both[:5]):
+        for key in ("classification", "prediction", "quality", "status"):
+            for li, t in enumerate(out.get(key) or []):
+                if t is None:
+                    continue
+                for b in range(2):
+                    ref = singles[b][ti][key][li][0]
+                    err = float((t[b] - ref).abs().max() / ref.abs().max().clamp_min(1e-9))
+                    assert err < 1e-3, (ti, key, li, b, err)
+                    checked += 1
+    assert checked >= 100

@@ -261,9 +261,11 @@ def test_bf16_configuration_is_pinned_op_by_op(golden):
     assert aggregated and heads
     top = lambda d: sorted(((round(v, 5), k) for k, v in d.items()), reverse=True)[:6]  # noqa: E731
     assert all(v < 1e-2 for v in aggregated.values()), top(aggregated)
-    assert all(v < 2e-2 for v in heads.values()), top(heads)
+    # measured (round 3, hi + lo activations in every Linear): motion class 1.29e-2, plan class 1.16e-2, every other head
+    # < 9e-3; anchor embeddings 9.7e-3, attention / FFN tokens < 4e-3
+    assert all(v < 1.6e-2 for v in heads.values()), top(heads)
     rest = {k: v for k, v in worst.items() if k not in aggregated and k not in heads}
-    assert all(v < 2e-2 for v in rest.values()), top(rest)
+    assert all(v < 1.2e-2 for v in rest.values()), top(rest)
 
 
 @pytest.mark.gpu

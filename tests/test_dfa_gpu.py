@@ -153,8 +153,12 @@ def test_dfa_module_matches_reference(golden, name, mode):
         assert rel_err(kps, z[f"{name}_key_points"]) < 5e-3
         s = wts.sum(dim=(2, 3, 4))                          # still a softmax per (anchor, group)
         assert torch.allclose(s, torch.ones_like(s), atol=1e-4)
-        assert rel_err(wts, z[f"{name}_weights"]) < 0.15   # exp() of bf16-accurate logits: peak weight moves by %
-        assert rel_err(out, z[f"{name}_output"]) < 2e-2    # BASELINE.json bf16 class (1e-2); measured <= 1.2e-2
+        assert rel_err(wts, z[f"{name}_weights"]) < 2e-2   # measured 1.4e-3 .. 5.1e-3 (round 2, bf16 activations: 0.15)
+        err = rel_err(out, z[f"{name}_output"])
+        print(f"bf16 module {name}: aggregated output rel err {err:.4e}, weights {rel_err(wts, z[f'{name}_weights']):.4e}")
+        # BASELINE.json bf16 class: 1e-2.  Measured 1.5e-4 .. 2.7e-4 since the single Linear layers keep the activation
+        # as a hi + lo bf16 pair like the chains (gemm_fwd_hilo_kernel); round 2, bf16 activations: 1.2e-2
+        assert err < 2e-3
 
 
 def test_dfa_module_trains(golden):

@@ -151,26 +151,40 @@ def segment_distances(a, b):
 
 
 def test_replayed_step_tracks_eager_step():
+    """The flat gradient of the replayed (hipGraph) step against the eagerly launched step, frame by frame (frames 5..9:
+    temporal caches warm, graphs replayed), decoder segment and encoder segment separately, with the decoder's discrete
+    choices (temporal top-k, motion-mode class) of the eager run replayed so that both runs follow the same branches.
+
+    What made this test impossible to hold tightly in round 2 (two EAGER runs 30-80 % apart in the gradient, loss equal to
+    3 digits) was not the chaos of a random-init net alone: the BatchNorm statistics were summed with fp32 atomics, the
+    sums moved in their last bit from run to run, bf16 activations flipped roundings, the pyramid ended 4e-3 apart
+    (tools/diag_forward_determinism.py) and the decoder's gradient is ~100x that sensitive (measured on CPU in plain
+    fp32 torch ops: tools/diag_grad_conditioning_cpu.py, profiles/r03_gradient_conditioning_cpu.txt).  The statistics are
+    accumulated in 64-bit fixed point now (order-independent): the forward is bitwise reproducible, what is left between
+    two runs is the summation order of the BACKWARD's float atomics -- measured 0.8-1.5e-2 (decoder) / 1.0-1.7e-2 (encoder)
+    between two eager runs as well as between eager and replayed (profiles/r03_eager_vs_replay_pinned.txt).  A replay defect
+    of the ROCm 7.2 kind (garbage of norm 1e27 in some gradient segment) or a missing / doubled segment is orders of
+    magnitude above the bound; the bound is 2-3x the measured noise floor."""
     warnings.filterwarnings("ignore")
     from hipad_amd import functional as HF
     HF.LIBRARY_CALLS.clear()
-    eager = run("eager", 10)[5:]     # frames 5 .. 9
-    graph = run("graph", 10)         # the same five frames, replayed
+    pinned_run("eager", 2, None, "decoder", 0)        # throw-away: MIOpen's find phase runs other solvers on first calls
+    eager, choices = pinned_run("eager", 10, None, "decoder")
+    again, _ = pinned_run("eager", 10, choices, "decoder")
+    graph, _ = pinned_run("graph", 10, choices, "decoder")
     # no Linear / LayerNorm of the decoder took a torch / library path on the way (VERDICT r01: silent fallbacks)
     assert not HF.LIBRARY_CALLS, dict(HF.LIBRARY_CALLS)
-    assert len(eager) == len(graph) == 5
-    for (le, ge), (lg, gg) in zip(eager, graph):
-        assert all(map(lambda v: v == v and abs(v) < 1e6, (le, ge, lg, gg))), (eager, graph)   # finite, not garbage
-        assert abs(le - lg) <= 0.03 * abs(le), (eager, graph)      # two eager runs: within 1.1 %
-    # The pre-clip gradient norm of a random-init net is dominated by a few chaotic components (atomic summation order in the
-    # aggregation / weight-gradient / BatchNorm kernels decides top-k and assignment ties) and single frames are heavy-tailed
-    # in EITHER launch mode.  Measured (profiles/r02z_graph_vs_eager_loss_gradnorm_noise.txt): two eager runs of frame 5:
-    # 570 vs 397; eager vs replay of frame 5 in three test runs: 380 vs 842, 1956 vs 405, 417 vs 421 -- next to ratios of
-    # 0.9 .. 1.3 on frames 6 and 7 of the same runs; losses always within 1.7 %.  A replay defect shows as 1e27..1e37 or NaN
-    # in every replayed frame (caught by the finiteness check above), a missing gradient segment as the same ratio in every
-    # frame: the MEDIAN ratio over five frames must be within x1.3.
-    ratios = sorted(g[1] / e[1] for e, g in zip(eager, graph))
-    assert 1 / 1.3 <= ratios[len(ratios) // 2] <= 1.3, (ratios, eager, graph)
+    assert len(eager) == len(again) == len(graph) == 5
+    floor = [segment_distances(a, b) for a, b in zip(eager, again)]
+    replay = [segment_distances(a, b) for a, b in zip(eager, graph)]
+    print("eager vs eager (noise floor):", floor, "\neager vs replayed:", replay)
+    for k, (e, g) in enumerate(zip(eager, graph)):
+        assert all(map(lambda v: v == v and abs(v) < 1e6, (e["loss"], e["norm"], g["loss"], g["norm"]))), (k, e["loss"], g["loss"])
+        assert abs(e["loss"] - g["loss"]) <= 1e-4 * abs(e["loss"]), (k, e["loss"], g["loss"])
+        assert abs(e["norm"] - g["norm"]) <= 0.02 * e["norm"], (k, e["norm"], g["norm"])
+        assert replay[k][0] <= 3e-2, (k, "decoder segment", replay, floor)
+        assert replay[k][1] <= 4e-2, (k, "encoder segment", replay, floor)
+        assert floor[k][0] <= 3e-2 and floor[k][1] <= 4e-2, (k, "two eager runs", floor)
 
 
 def test_two_part_backward_equals_one_backward():
