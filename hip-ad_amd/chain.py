@@ -67,6 +67,13 @@ def packed_numel(rows, depth):
     return ((rows + 15) // 16) * ((depth + 31) // 32) * 512
 
 
+def _shadow_ok(weight):
+    """The optimiser-kept copies still describe the parameter (hipad_amd.optim.shadow_is_current: a torch write since the
+    last refresh -- load_state_dict, checkpoint resume -- triggers a refresh, or sends the caller to its own cache)."""
+    from .optim import shadow_is_current
+    return shadow_is_current(weight)
+
+
 def bf16_pair(weight):
     """(P(W), P(W^T)): the chain kernels' bf16 operand copies of a 2-D fp32 parameter W [N][K].
 
@@ -74,7 +81,7 @@ def bf16_pair(weight):
     ``weight._hipad_shadow``; otherwise the pair is derived here and cached on (storage address, version counter), so
     in-place torch updates are seen."""
     pair = getattr(weight, "_hipad_shadow", None)
-    if pair is not None:
+    if pair is not None and _shadow_ok(weight):
         return pair
     # cached ON the parameter object (a table keyed by id() would hand a new parameter that reuses a freed one's id,
     # address, version and shape the old one's copies)
@@ -110,7 +117,7 @@ class _L:
         if self.rows is None:
             return bf16_pair(self.weight)
         table = getattr(self.weight, "_hipad_shadow_rows", None)
-        if table is not None and self.rows in table:
+        if table is not None and self.rows in table and _shadow_ok(self.weight):
             return table[self.rows]
         hit = getattr(self.weight, "_hipad_pair_rows", None)
         stamp = (self.weight.data_ptr(), self.weight._version, tuple(self.weight.shape))

@@ -618,8 +618,34 @@ extern "C" {
 
 void hipad_chain_debug_stamps(unsigned long long *device_buffer) { g_stamps = device_buffer; }
 
+// every argument check of a call happens before its first launch (an EINVAL must not leave half the batches enqueued)
+static int check_chain(const hipad_chain &s) {
+  if (s.nlayers < 1 || s.nlayers > HIPAD_CHAIN_MAX_LAYERS || s.M <= 0 || !s.x0 || !s.out) return HIPAD_EINVAL;
+  for (int l = 0; l < s.nlayers; ++l) {
+    const hipad_chain_layer &sl = s.layers[l];
+    if (!ch_check_dims(sl.K, sl.N) || !sl.w) return HIPAD_EINVAL;
+    if (l > 0 && sl.K != s.layers[l - 1].N) return HIPAD_EINVAL;
+    if ((uintptr_t)sl.w & 15) return HIPAD_EINVAL;
+    if ((sl.flags & 2) && l + 1 == s.nlayers && s.out_scale) return HIPAD_EINVAL;  // Scale after a LayerNorm: unused
+  }
+  return HIPAD_OK;
+}
+
+static int check_chain_grad(const hipad_chain_grad &s) {
+  if (s.nlayers < 1 || s.nlayers > HIPAD_CHAIN_MAX_LAYERS || s.M <= 0 || !s.dout || !s.dy || !s.save) return HIPAD_EINVAL;
+  for (int l = 0; l < s.nlayers; ++l) {
+    const hipad_chain_grad_layer &sl = s.layers[l];
+    if (!ch_check_dims(sl.K, sl.N)) return HIPAD_EINVAL;
+    const bool need_wt = l > 0 || s.dx;
+    if (need_wt && (!sl.wt || ((uintptr_t)sl.wt & 15))) return HIPAD_EINVAL;
+  }
+  return HIPAD_OK;
+}
+
 int hipad_chain_forward(const hipad_chain *chains, int nchains, hipad_stream_t stream_) {
   if (!chains || nchains <= 0) return HIPAD_EINVAL;
+  for (int i = 0; i < nchains; ++i)
+    if (check_chain(chains[i]) != HIPAD_OK) return HIPAD_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   int maxM = 0;
   for (int i = 0; i < nchains; ++i) maxM = chains[i].M > maxM ? chains[i].M : maxM;
@@ -662,6 +688,8 @@ int hipad_chain_forward(const hipad_chain *chains, int nchains, hipad_stream_t s
 
 int hipad_chain_backward_dx(const hipad_chain_grad *chains, int nchains, hipad_stream_t stream_) {
   if (!chains || nchains <= 0) return HIPAD_EINVAL;
+  for (int i = 0; i < nchains; ++i)
+    if (check_chain_grad(chains[i]) != HIPAD_OK) return HIPAD_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   int maxM = 0;
   for (int i = 0; i < nchains; ++i) maxM = chains[i].M > maxM ? chains[i].M : maxM;

@@ -243,8 +243,8 @@ int hipad_adamw_step(float *param, float *grad, float *exp_avg, float *exp_avg_s
   if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0) return HIPAD_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   float *partial = (float *)workspace;
+  if (shadow_bf16 && ((uintptr_t)shadow_bf16 & 7) != 0) return HIPAD_EINVAL;   // every argument check before the first launch
   hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(kNormBlocks), dim3(256), 0, stream, partial, grad, (long)(n >> 2), (long)n);
-  if (shadow_bf16 && ((uintptr_t)shadow_bf16 & 7) != 0) return HIPAD_EINVAL;
   AdamCoef k{lr0, lr1, beta1, beta2, eps, weight_decay, max_norm, {0, 0, 1.f, 0, 1.f}};
   if (sched) k.sched = *sched;
   hipLaunchKernelGGL(adamw_flat_kernel, dim3(2048), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, (long)n,

@@ -106,9 +106,13 @@ class FlatGrads:
     def zero(self):
         self.flat.zero_()
 
-    def check_views(self):
-        """Autograd may replace .grad when it was set to None in between; re-attach if so."""
+    def check_views(self, segment=None):
+        """Autograd may replace .grad when it was set to None in between; re-attach if so.  ``segment`` ("early" / "late")
+        limits the walk to one segment: the early one must be put right BEFORE its all-reduce starts on the side stream
+        (a copy into a buffer that is being reduced would race with the collective)."""
         for p, off in zip(self.params, self.offsets):
+            if segment is not None and (off < self.split) != (segment == "early"):
+                continue
             n = p.numel()
             if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + off * self.flat.element_size():
                 g = p.grad

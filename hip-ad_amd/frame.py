@@ -240,6 +240,9 @@ class TrainStep:
         """Start the all-reduce of the first segment on the communication stream (call after part_loss_backward)."""
         if self.world == 1:
             return
+        if not self.grads.flat.is_cuda:       # host tensors (gloo tests): no streams, the collective runs in place
+            self.grads.all_reduce_mean(segment="early")
+            return
         if self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream()
         self._comm_stream.wait_stream(torch.cuda.current_stream())
@@ -249,6 +252,9 @@ class TrainStep:
     def reduce_late(self):
         """All-reduce the second segment and join the communication stream (call after part_backward_encoder)."""
         if self.world == 1:
+            return
+        if not self.grads.flat.is_cuda:
+            self.grads.all_reduce_mean(segment="late")
             return
         if self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream()
@@ -266,9 +272,10 @@ class TrainStep:
         self.exchange_counts()
         loss = self.part_loss_backward()  # gradients are zero here: update() clears what it applied
         if img.is_cuda:
+            self.grads.check_views("early")       # before the segment's all-reduce starts (it runs on a side stream)
             self.reduce_early()
             self.part_backward_encoder()
-            self.grads.check_views()
+            self.grads.check_views("late")
             self.reduce_late()
         else:
             self.part_backward_encoder()
@@ -303,6 +310,11 @@ class GraphedTrainStep:
         self.model, self.frames = model, frames
         self.inner = TrainStep(model, cfg, comm_dtype=comm_dtype, capturable=True)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        import os
+        self.split_forward = self.world > 1 or os.environ.get("HIPAD_SPLIT_FORWARD") == "1"
+        # split_backward: the backward as TWO graphs cut at the pyramid levels (losses + decoder | FPN + backbone), so that
+        # the decoder segment's all-reduce can travel on a side stream while the encoder's backward replays
+        self.split_backward = self.split_forward and os.environ.get("HIPAD_SPLIT_BACKWARD", "1") == "1"
         dec = model.head.onedecoder_head
         dec.with_instance_id = False
         if model.use_grid_mask:
@@ -356,17 +368,20 @@ class GraphedTrainStep:
         # is used by the eagerly launched step (TrainStep.__call__) only: captured, the encoder's backward as a separate
         # autograd.backward call made ROCm 7.2 die in capture_end in every arrangement tried (tools/diag_graph_split.py,
         # DESIGN.md section 4), and there is no 2-GPU box in this build loop to debug an in-graph overlap on.
-        import os
-        self.split_forward = self.world > 1 or os.environ.get("HIPAD_SPLIT_FORWARD") == "1"
         self.graph_f = torch.cuda.CUDAGraph()
-        self.graph_l = None
+        self.graph_l = self.graph_e = None
         if self.split_forward:
             with torch.cuda.graph(self.graph_f):
-                self.inner.part_forward(self.img, self.data)
+                self.inner.part_forward(self.img, self.data, keep_levels=self.split_backward)
             self.graph_l = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_l, pool=self.graph_f.pool()):
-                self.loss = self.inner.part_loss_backward(whole=True)
-                self.inner.part_backward_encoder()
+                self.loss = self.inner.part_loss_backward(whole=not self.split_backward)
+                if not self.split_backward:
+                    self.inner.part_backward_encoder()
+            if self.split_backward:
+                self.graph_e = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_e, pool=self.graph_f.pool()):
+                    self.inner.part_backward_encoder()
         else:
             with torch.cuda.graph(self.graph_f):
                 self.inner.part_forward(self.img, self.data)
@@ -385,7 +400,12 @@ class GraphedTrainStep:
         if self.graph_l is not None:
             self.inner.exchange_counts()
             self.graph_l.replay()
-        if self.world > 1:
+        if self.graph_e is not None:
+            # [F | counts | L: losses + decoder backward | early all-reduce (side stream) || E: encoder backward | late | B]
+            self.inner.reduce_early()
+            self.graph_e.replay()
+            self.inner.reduce_late()
+        elif self.world > 1:
             self.inner.grads.all_reduce_mean()
         self.graph_b.replay()
 
@@ -414,9 +434,9 @@ class GraphedTrainStep:
 
     def _fwd_bwd(self):
         # gradients start at zero: FlatGrads allocates them so and every update() clears them again
-        self.inner.part_forward(self.img, self.data)
+        self.inner.part_forward(self.img, self.data, keep_levels=self.split_backward)
         self.inner.exchange_counts()
-        loss = self.inner.part_loss_backward(whole=True)
+        loss = self.inner.part_loss_backward(whole=not self.split_backward)
         self.inner.part_backward_encoder()
         return loss
 

@@ -128,6 +128,7 @@ class _ZeroArena:
 
     def __init__(self):
         self.buf, self.used, self.high = None, 0, 0
+        self.generation = 0     # bumped by every reset(): a slice handed out before the reset may have been handed out again
 
     def reset(self, device, capacity=1 << 20):
         if self.buf is None or self.buf.device != torch.device(device) or self.buf.numel() < max(capacity, self.high):
@@ -135,6 +136,7 @@ class _ZeroArena:
         else:
             self.buf[:max(self.used, 1)].zero_()
         self.used = 0
+        self.generation += 1
 
     def take(self, n, device):
         n = (n + 63) // 64 * 64
@@ -159,6 +161,7 @@ class _BatchNormAct(Function):
         n = _lib.BN_REPLICAS * 2 * c * _lib.BN_SUM_FLOATS
         sums = BN_ARENA.take(n, x.device)
         ctx.gsums = BN_ARENA.take(n, x.device) if any(ctx.needs_input_grad[:4]) else None
+        ctx.arena_generation = BN_ARENA.generation
         y, save = _lib.bn_forward(x, residual, weight.detach(), bias.detach(), running_mean, running_var, sums, eps, momentum, relu)
         ctx.save_for_backward(x, y if relu else None, save)
         ctx.weight, ctx.bias, ctx.has_res = weight, bias, residual is not None
@@ -184,6 +187,9 @@ class _BatchNormAct(Function):
             else:
                 targets.append(None)
         gsums, ctx.gsums = ctx.gsums, None          # the reserved slice is zero only once (retain_graph: fresh zeros after)
+        if gsums is not None and ctx.arena_generation != BN_ARENA.generation:
+            gsums = None    # another training forward reset the arena since ours (gradient accumulation, an auxiliary
+            #                 forward): the reserved slice may hold that forward's sums by now -- take fresh zeros
         if gsums is None:
             gsums = torch.zeros(_lib.BN_REPLICAS * 2 * x.shape[1] * _lib.BN_SUM_FLOATS, dtype=torch.float32, device=x.device)
         dx, dres = _lib.bn_backward(dy, y, x, save, weight.detach(), gsums, targets[0], targets[1],

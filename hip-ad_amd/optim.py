@@ -158,10 +158,20 @@ class FlatAdamW:
                                               pk["tiles"], _lib.stream_ptr(dev)), "hipad_pack_weights")
 
     def refresh_shadow(self):
-        """Re-derive the bf16 copies from the fp32 parameters (after loading a checkpoint / writing p.data)."""
+        """Re-derive the bf16 copies from the fp32 parameters.  Runs by itself when a consumer of a copy finds that torch
+        wrote the parameter since the copies were made (load_state_dict, checkpoint resume, ``p.copy_(...)``): every
+        parameter is stamped with its version counter here and after every ``step()`` (the optimiser kernel itself
+        updates parameters through raw pointers and does not move the counters), and ``shadow_is_current`` compares."""
         if self.shadow is not None:
             _lib.shadow_bf16(self.shadow, self.flat_p)
         self._pack_chain_operands()
+        self._stamp()
+
+    def _stamp(self):
+        import weakref
+        ref = weakref.WeakMethod(self.refresh_shadow)
+        for p in self.params:
+            p._hipad_shadow_stamp = (p._version, p.data_ptr(), ref)
 
     def shadow_of(self, p):
         """bf16 view of parameter ``p`` inside the shadow buffer (None when no shadow is kept)."""
@@ -182,3 +192,24 @@ class FlatAdamW:
                         self.lrs[1], self.betas, self.eps, self.weight_decay, self.max_norm, self.step_count,
                         self._stats, self._ws, zero_grad=zero_grad, sched=self._sched, shadow=self.shadow)
         self._pack_chain_operands()
+
+
+def shadow_is_current(weight):
+    """True when the bf16 copies an optimiser attached to ``weight`` (``_hipad_shadow``, ``_hipad_shadow_rows``,
+    ``_hipad_bf16``) may be used: torch has not written the parameter since they were made -- or it has, and the owning
+    optimiser could be asked to re-derive them (done here).  False: the caller falls back to deriving its own copy.
+    Replacing a parameter's storage (``p.data = other``) detaches it from the flat buffers: that is an error."""
+    stamp = getattr(weight, "_hipad_shadow_stamp", None)
+    if stamp is None:
+        return True                      # copies attached by hand (tests): the caller's responsibility
+    version, ptr, refresh = stamp
+    if weight.data_ptr() != ptr:
+        raise RuntimeError("a parameter managed by FlatAdamW was given new storage (p.data = ...): its flat-buffer views and "
+                           "bf16 operand copies no longer follow it; write into it with p.copy_() / load_state_dict instead")
+    if weight._version == version:
+        return True
+    fn = refresh()
+    if fn is None:
+        return False
+    fn()                                 # re-derives and re-stamps every copy of that optimiser
+    return True

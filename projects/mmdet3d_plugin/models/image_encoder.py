@@ -77,6 +77,10 @@ class Conv2d(nn.Conv2d):
 
     def forward(self, x):
         shadow = getattr(self.weight, "_hipad_bf16", None)
+        if shadow is not None:
+            from hipad_amd.optim import shadow_is_current
+            if not shadow_is_current(self.weight):      # written by torch since the copy was made and nobody to refresh it
+                shadow = None
         if (shadow is not None and x.is_cuda and torch.is_autocast_enabled() and self.padding_mode == "zeros"
                 and torch.get_autocast_dtype("cuda") == torch.bfloat16):
             if torch.is_grad_enabled() and self.weight.requires_grad:

@@ -90,7 +90,7 @@ def test_config5_stage2_resnet101_1600x640_trains():
 def test_config4_stage2_bs2():
     """BASELINE.json config 4 (hipad_b2d_stage2, 2 frames per GPU): two finite training steps at bs = 2, and -- in eval
     mode, stochastic layers off, cold instance banks -- every head output of the bs = 2 batch equals the outputs of the
-    same two frames run as bs = 1 passes (1e-3 of the tensor's largest magnitude: samples do not mix anywhere)."""
+    same two frames run as bs = 1 passes (5e-3 of the tensor's largest magnitude: samples do not mix anywhere)."""
     import copy
     from hipad_amd.frame import SyntheticFrames, TrainStep, build_detector
     warnings.filterwarnings("ignore")
@@ -135,6 +135,9 @@ def test_config4_stage2_bs2():
                 for b in range(2):
                     ref = singles[b][ti][key][li][0]
                     err = float((t[b] - ref).abs().max() / ref.abs().max().clamp_min(1e-9))
-                    assert err < 1e-3, (ti, key, li, b, err)
+                    # fp32 encoder, bf16-operand decoder: the fp32 convolutions of 12 and of 6 images differ in the last
+                    # bits, the decoder's operand rounding turns that into <= 1.6e-3 by the last layer (measured); a
+                    # sample reading another sample's rows is an O(1) error
+                    assert err < 5e-3, (ti, key, li, b, err)
                     checked += 1
     assert checked >= 100

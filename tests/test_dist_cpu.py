@@ -176,3 +176,89 @@ def test_reduce_mean_refuses_to_run_inside_a_capture_and_count_exchange_phases()
     ex.begin("use")
     assert torch.equal(ex.exchange(torch.zeros(2)), a)   # single process: the collected values come back
     ex.begin("direct")
+
+
+def _worker_replay_schedule(rank, world, port, q):
+    """GraphedTrainStep._replay at world 2 with the backward split at the pyramid cut: the real control flow (and the
+    real TrainStep.reduce_early / reduce_late / exchange_counts) around stand-in graphs that do a toy model's work on
+    the host -- [F | counts | L: decoder backward | early all-reduce || E: encoder backward | late all-reduce | B]."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from hipad_amd import dist as D
+    from hipad_amd.compat import count_exchange
+    from hipad_amd.frame import GraphedTrainStep, TrainStep
+    D.init_from_env("gloo")
+    torch.manual_seed(3)
+    decoder, encoder = torch.nn.Linear(8, 4), torch.nn.Linear(6, 8)      # flat layout: [decoder | encoder]
+    params = list(decoder.parameters()) + list(encoder.parameters())
+    fg = D.FlatGrads(params)
+    fg.set_split(params[2])
+    order, state = [], {}
+    inner = object.__new__(TrainStep)
+    inner.grads, inner.world, inner._comm_stream = fg, world, None
+    plain_all_reduce = fg.all_reduce_mean
+    fg.all_reduce_mean = lambda group=None, segment=None: (order.append("reduce_" + str(segment)), plain_all_reduce(group, segment))[1]
+
+    class Graph:
+        def __init__(self, name, fn):
+            self.name, self.fn = name, fn
+
+        def replay(self):
+            order.append(self.name)
+            self.fn()
+
+    def forward():
+        x = torch.full((3, 6), float(rank + 1))
+        # the "pyramid levels": a VIEW of the encoder's output, as the detector's reshaped levels are -- capturing the
+        # gradient at a node's own output makes torch 2.10 release that node's buffers in the first backward
+        state["cut"] = encoder(x).view(3, 8)
+        state["loss"] = decoder(state["cut"]).square().sum()
+        count_exchange.begin("collect")
+        count_exchange.exchange(torch.tensor([float(rank + 1)]))
+        count_exchange.begin("direct")
+
+    def decoder_backward():
+        count_exchange.begin("use")
+        state["count"] = float(count_exchange.exchange(torch.zeros(1)))
+        count_exchange.begin("direct")
+        torch.autograd.backward([state["loss"]], inputs=list(decoder.parameters()) + [state["cut"]])
+
+    def encoder_backward():
+        state["early_at_e"] = fg.flat[:fg.split].clone()        # must already be the cross-rank mean
+        torch.autograd.backward([state["cut"]], [state["cut"].grad])
+
+    g = object.__new__(GraphedTrainStep)
+    g.inner, g.world = inner, world
+    g.graph_f, g.graph_l = Graph("F", forward), Graph("L", decoder_backward)
+    g.graph_e, g.graph_b = Graph("E", encoder_backward), Graph("B", lambda: state.__setitem__("final", fg.flat.clone()))
+    plain_exchange = inner.exchange_counts
+    inner.exchange_counts = lambda: (order.append("counts"), plain_exchange())[1]
+    # reference: local gradient of this rank, then the mean over the ranks
+    forward()
+    state["loss"].backward()
+    local = fg.flat.clone()
+    both = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(both, local)
+    expect = torch.stack(both).mean(0)
+    fg.zero()
+    g._replay()
+    ok_order = order == ["F", "counts", "L", "reduce_early", "E", "reduce_late", "B"]
+    ok_vals = bool(torch.allclose(state["final"], expect, rtol=1e-6, atol=1e-7))
+    ok_early = bool(torch.allclose(state["early_at_e"], expect[:fg.split], rtol=1e-6, atol=1e-7))
+    ok_count = abs(state["count"] - (1 + 2) / 2) < 1e-6           # mean of the ranks' counts reached graph L
+    q.put((rank, ok_order and ok_vals and ok_early and ok_count, dict(order=order, vals=ok_vals, early=ok_early, count=state["count"])))
+    dist.destroy_process_group()
+
+
+def test_replay_schedule_overlaps_the_early_segment_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_replay_schedule, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    results = [q.get(timeout=5) for _ in range(world)]
+    assert all(ok for _, ok, _ in results), results

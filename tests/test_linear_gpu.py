@@ -111,7 +111,7 @@ def test_linear_relu_ln_unit_matches_unfused(M, N, K):
     # the ReLU gate is evaluated on bf16-operand pre-activations in the kernel: a fraction of a percent of the units
     # sit on the other side of zero in fp32 (see test_linear_forward_backward); compare under the kernel's own gate
     from hipad_amd import lib
-    gate = lib.linear_forward(x, w, b, True) > 0
+    gate = lib.linear_relu_ln_forward(x, w, b, ga, be, 1e-5)[1] > 0     # the fused unit's own ReLU output
     assert float((gate != (pre.detach() > 0)).float().mean()) < 1e-2
     act = pre * gate
     yr = torch.nn.functional.layer_norm(act, (N,), rs[2], rs[3], 1e-5)

@@ -99,3 +99,33 @@ def test_optimizer_keeps_the_chain_operands_current():
             assert w.data_ptr() == p._hipad_shadow[0].data_ptr()
             assert torch.equal(w, CH.pack_fragments(p.detach()))
             assert torch.equal(wt, CH.pack_fragments(p.detach().t()))
+
+
+def test_bf16_copies_follow_a_checkpoint_load():
+    """weights written by torch AFTER the optimiser took the parameters over (load_state_dict, checkpoint
+    resume, p.copy_) must reach the bf16 operand copies the chain kernels and the encoder's convolutions read -- the
+    copies are stamped with the parameters' version counters and re-derived on the first use after such a write."""
+    from hipad_amd import chain as CH
+    from hipad_amd.optim import FlatAdamW, shadow_is_current
+    ps = make_params(6)
+    opt = FlatAdamW([(ps[:4], 2e-3), (ps[4:], 1e-3)], weight_decay=0.0, max_norm=None, bf16_shadow=True)
+    w = ps[1]                                         # (256, 256): has a chain operand pair and a flat bf16 shadow
+    shadow = opt.shadow_of(w)
+    old_pair = CH.bf16_pair(w)[0].clone()
+    new = torch.randn_like(w) * 3
+    with torch.no_grad():
+        w.copy_(new)                                  # what load_state_dict does
+    pair = CH.bf16_pair(w)                            # notices the version counter moved, has the optimiser re-derive
+    assert torch.equal(pair[0], CH.pack_fragments(new)) and not torch.equal(pair[0], old_pair)
+    assert torch.equal(pair[1], CH.pack_fragments(new.t()))
+    assert torch.equal(shadow, new.to(torch.bfloat16))            # the flat shadow (convolution weights) as well
+    assert shadow_is_current(w)
+    # the optimiser's own updates (raw pointers, no version bump) keep the copies current without another refresh
+    for p in ps:
+        p.grad.copy_(torch.randn_like(p))
+    opt.step()
+    assert torch.equal(CH.bf16_pair(w)[0], CH.pack_fragments(w.detach()))
+    # new storage behind the optimiser's back is an error, not a silent use of stale copies
+    w.data = w.data.clone()
+    with pytest.raises(RuntimeError):
+        CH.bf16_pair(w)
