@@ -510,8 +510,9 @@ def main():
                    grad_allreduce_dtype=("none (1 rank)" if world == 1 else a.comm_dtype),
                    launch="eager (decoder-segment all-reduce overlapped with the encoder's backward)" if a.eager else
                    ("hipGraph replay: forward+losses+backward graph, clip+AdamW graph" if world == 1 else
-                    "hipGraph replay: forward graph | positive-count all-reduce | losses+backward graph | flat-gradient "
-                    "all-reduce (RCCL) | clip+AdamW graph"),
+                    "hipGraph replay: forward graph | positive-count all-reduce | losses + decoder-backward graph | "
+                    "all-reduce of the decoder gradient segment (RCCL, side stream) overlapped with the encoder-backward "
+                    "graph | all-reduce of the encoder segment | clip+AdamW graph"),
                    with_cp=False, with_cp_note="activation checkpointing of the backbone (reference config: with_cp=True, "
                    "projects/configs/hipad_b2d_stage2.py:119) is OFF: 288 GB of HBM hold the activations, so the "
                    "reference's backbone re-computation in the backward is not part of this step",

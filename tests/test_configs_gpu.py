@@ -138,6 +138,8 @@ def test_config4_stage2_bs2():
                     # fp32 encoder, bf16-operand decoder: the fp32 convolutions of 12 and of 6 images differ in the last
                     # bits, the decoder's operand rounding turns that into <= 1.6e-3 by the last layer (measured); a
                     # sample reading another sample's rows is an O(1) error
-                    assert err < 5e-3, (ti, key, li, b, err)
+                    # (the motion head sees sin / cos of metres x 10000^(i/128) phases of the predicted boxes: the same noise
+                    # reaches 1.3e-2 .. 8.6e-2 there, cf. tests/test_decoder.py; it is held to "not another sample's rows")
+                    assert err < (0.25 if ti == 4 else 5e-3), (ti, key, li, b, err)
                     checked += 1
     assert checked >= 100
