@@ -14,6 +14,9 @@ Workloads
                softmax-weight / attention kernels, bf16 GEMMs) -> the reference's losses with the Hungarian
                target assignment on the device (criterion.py, hipad_linear_assignment) -> backward -> gradient
                all-reduce (RCCL) -> clip -> AdamW.  --plan-queries 48 gives BASELINE.json's 6x8 wording.
+  stage2_full_frames   the same training step fed through the data pipeline: uint8 1600x900 camera
+               frames resident in HBM -> GroupInBatchSampler -> per-sequence augmentation draw -> device image pipeline
+               (hipad_amd.imgpipe) -> GridMask -> step (hipad_amd.dataflow.SequenceFrames).
   daf_stage2   the aggregation path of one stage-2 frame: for each of the 6 decoder layers the
                four deformable-aggregation calls (det 900x13, map 100x300, plan 480x90, ego 1x13
                key points; 6 cams x 4 levels x 8 groups; C=256, bf16 pyramid rows, fp32 arithmetic) forward AND backward on the
@@ -47,7 +50,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="stage2_full",
-                    choices=("stage2_full", "daf_stage2", "stage2_infer", "stage2_r101_1600", "stage1_fp32"))
+                    choices=("stage2_full", "stage2_full_frames", "daf_stage2", "stage2_infer", "stage2_r101_1600",
+                             "stage1_fp32"))
     ap.add_argument("--plan-queries", type=int, default=480, choices=(48, 480))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch the step kernel by kernel instead of replaying hipGraphs")
@@ -224,14 +228,21 @@ class DafStage2:
 class Stage2Full:
     """One training step of the whole model per frame (see module docstring)."""
 
-    def __init__(self, device, seed, plan_queries=480, bs=1, eager=False, hw=(256, 704), stage=2, comm_dtype=None, **build):
+    def __init__(self, device, seed, plan_queries=480, bs=1, eager=False, hw=(256, 704), stage=2, comm_dtype=None,
+                 pipeline_frames=False, **build):
         import warnings
         warnings.filterwarnings("ignore", category=DeprecationWarning)
         from hipad_amd.frame import GraphedTrainStep, SyntheticFrames, TrainStep, build_detector
         torch.manual_seed(1234)  # identical initial weights on every rank (then broadcast anyway)
         self.model, self.cfg = build_detector(stage=stage, input_hw=hw, plan_queries=plan_queries, device=device, **build)
         self.model.train()
-        self.frames = SyntheticFrames(bs=bs, input_hw=hw, device=device, seed=seed)
+        if pipeline_frames:
+            # stored uint8 camera frames (HBM resident) -> sequence-grouped sampler -> per-sequence image augmentation ->
+            # device image pipeline (resize / crop / flip / rotate / normalise, two launches per sample) -> the step
+            from hipad_amd.dataflow import SequenceFrames
+            self.frames = SequenceFrames(bs=bs, input_hw=hw, device=device, seed=seed)
+        else:
+            self.frames = SyntheticFrames(bs=bs, input_hw=hw, device=device, seed=seed)
         self.hw, self.stage = hw, stage
         self.bs, self.plan_queries, self.eager = bs, plan_queries, eager
         if eager:
@@ -453,13 +464,15 @@ def main():
         raise SystemExit(f"bench: --gpus {a.gpus} but the launcher started {world} rank(s); refusing to report "
                          f"a {world}-rank number as the {a.gpus}-GPU point")
     dev = torch.device("cuda", local)
-    full = a.workload in ("stage2_full", "stage2_r101_1600", "stage1_fp32")
+    full = a.workload in ("stage2_full", "stage2_full_frames", "stage2_r101_1600", "stage1_fp32")
     infer = a.workload == "stage2_infer"
     extra = {}
     if a.workload == "stage2_r101_1600":   # BASELINE.json config 5: the pyramid (522 MB fp32) leaves the Infinity Cache
         extra = dict(hw=(640, 1600), backbone_depth=101)
     elif a.workload == "stage1_fp32":      # BASELINE.json config 2
         extra = dict(stage=1, encoder_dtype=torch.float32)
+    elif a.workload == "stage2_full_frames":   # the same step fed through the data pipeline
+        extra = dict(pipeline_frames=True)
     comm = torch.bfloat16 if (a.comm_dtype == "bf16" and world > 1) else None
     wl = (Stage2Full(dev, seed=rank, plan_queries=a.plan_queries, bs=a.bs, eager=a.eager, comm_dtype=comm, **extra) if full
           else Stage2Infer(dev, seed=rank, plan_queries=a.plan_queries) if infer
@@ -497,7 +510,11 @@ def main():
         note("frame roofline census done")
     if full:
         hw_txt = "%dx%d" % (wl.hw[1], wl.hw[0])
-        enc_txt = {"stage2_full": "ResNet50+FPN bf16 channels-last", "stage2_r101_1600": "ResNet101+FPN bf16 channels-last "
+        enc_txt = {"stage2_full": "ResNet50+FPN bf16 channels-last",
+                   "stage2_full_frames": "ResNet50+FPN bf16 channels-last, INPUT THROUGH THE DATA PIPELINE (six uint8 1600x900 "
+                   "frames per sample resident in HBM -> sequence-grouped sampler -> per-sequence resize/crop/flip/rotate draw "
+                   "-> device image pipeline, Pillow-exact, + normalisation -> GridMask -> step; augmented projection matrices "
+                   "composed per frame)", "stage2_r101_1600": "ResNet101+FPN bf16 channels-last "
                    "(BASELINE config 5: 510 000 pyramid positions, 522 MB fp32, outside the Infinity Cache)",
                    "stage1_fp32": "ResNet50+FPN fp32 (BASELINE config 2: hipad_b2d_stage1, no motion head)"}[a.workload]
         workload = (f"{a.workload}: one training step (forward + the reference's losses with device-side Hungarian target "

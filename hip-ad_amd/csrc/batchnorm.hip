@@ -149,7 +149,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(uint4 *__restrict__ y, co
                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
                                                        float *__restrict__ running_mean, float *__restrict__ running_var,
                                                        float *__restrict__ save /* [2C]: mean, rstd */, long rows, int C,
-                                                       float eps, float momentum, int relu, long rows_per_block) {
+                                                       float eps, float momentum, int relu, long rows_per_block,
+                                                       long y_group_rows, long y_group_stride /* in rows */) {
   const int tpr = C >> 3, rpi = 256 / tpr;
   const int lc = threadIdx.x % tpr, lr = threadIdx.x / tpr;
   const float inv_m = 1.f / (float)rows;
@@ -224,7 +225,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(uint4 *__restrict__ y, co
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = o[k] > 0.f ? o[k] : 0.f;
       }
-      if (ok[j]) y[(r + (long)j * rpi) * tpr + lc] = pack8(o);
+      if (ok[j]) {
+        // output row: groups of y_group_rows consecutive rows sit y_group_stride rows apart (one group = one sample's
+        // block of a level inside the flat pyramid; a plain tensor is one group)
+        const long rr = r + (long)j * rpi;
+        const long g = rr / y_group_rows;
+        y[(g * y_group_stride + (rr - g * y_group_rows)) * tpr + lc] = pack8(o);
+      }
     }
   }
 }
@@ -384,10 +391,24 @@ extern "C" {
 
 int hipad_bn_supported(long long rows, int channels) { return bn_shape_ok((long)rows, channels) ? 1 : 0; }
 
+int hipad_bn_forward_grouped(void *y, float *save, float *sums, const void *x, const void *residual, const float *gamma,
+                             const float *beta, float *running_mean, float *running_var, long long rows, int channels,
+                             float eps, float momentum, int relu, long long y_group_rows, long long y_group_stride_rows,
+                             hipad_stream_t stream_);
+
 int hipad_bn_forward(void *y, float *save, float *sums, const void *x, const void *residual, const float *gamma,
                      const float *beta, float *running_mean, float *running_var, long long rows, int channels, float eps,
                      float momentum, int relu, hipad_stream_t stream_) {
+  return hipad_bn_forward_grouped(y, save, sums, x, residual, gamma, beta, running_mean, running_var, rows, channels, eps,
+                                  momentum, relu, rows, rows, stream_);
+}
+
+int hipad_bn_forward_grouped(void *y, float *save, float *sums, const void *x, const void *residual, const float *gamma,
+                             const float *beta, float *running_mean, float *running_var, long long rows, int channels,
+                             float eps, float momentum, int relu, long long y_group_rows, long long y_group_stride_rows,
+                             hipad_stream_t stream_) {
   if (!y || !save || !sums || !x || !gamma || !beta) return HIPAD_EINVAL;
+  if (y_group_rows <= 0 || rows % y_group_rows || y_group_stride_rows < y_group_rows) return HIPAD_EINVAL;
   if ((running_mean == nullptr) != (running_var == nullptr)) return HIPAD_EINVAL;
   if (!bn_shape_ok((long)rows, channels)) return HIPAD_ERANGE;
   if ((((uintptr_t)y | (uintptr_t)x | (uintptr_t)residual) & 15) != 0) return HIPAD_EINVAL;
@@ -400,7 +421,7 @@ int hipad_bn_forward(void *y, float *save, float *sums, const void *x, const voi
                      channels, rpb);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, stream, (uint4 *)y, (const uint4 *)x,
                      (const uint4 *)residual, (const long long *)sums, gamma, beta, running_mean, running_var, save, (long)rows, channels, eps,
-                     momentum, relu ? 1 : 0, rpb);
+                     momentum, relu ? 1 : 0, rpb, (long)y_group_rows, (long)y_group_stride_rows);
   return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
 }
 

@@ -426,10 +426,16 @@ class GraphedTrainStep:
         done.record()
         for k in self._gt_keys:
             _copy_tree(self.data[k], data[k])
+        for k in ("projection_mat", "image_wh"):    # per-frame camera geometry (image augmentation): into the static buffers
+            if data[k].data_ptr() != self.data[k].data_ptr():
+                self.data[k].copy_(data[k], non_blocking=True)
         if self.model.use_grid_mask and getattr(self.model.grid_mask, "_last_h", None) is not None:
             self.model.grid_mask.randomize(self.img.device)
 
     def _ts_from(self, data):
+        host = data.get("timestamp_host")           # a frame source with its own clock (hipad_amd.dataflow.SequenceFrames)
+        if host is not None:
+            return host
         return torch.full((self.frames.bs,), 0.5 * (self.frames.step - 1), dtype=torch.float64)
 
     def _fwd_bwd(self):

@@ -156,13 +156,22 @@ class _BatchNormAct(Function):
     """relu?(batch_norm(x) (+ residual)) on the two fused kernels (csrc/batchnorm.hip); x bf16 channels-last."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, running_mean, running_var, eps, momentum, relu):
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, eps, momentum, relu, out=None):
         c = x.shape[1]
         n = _lib.BN_REPLICAS * 2 * c * _lib.BN_SUM_FLOATS
         sums = BN_ARENA.take(n, x.device)
         ctx.gsums = BN_ARENA.take(n, x.device) if any(ctx.needs_input_grad[:4]) else None
         ctx.arena_generation = BN_ARENA.generation
-        y, save = _lib.bn_forward(x, residual, weight.detach(), bias.detach(), running_mean, running_var, sums, eps, momentum, relu)
+        y, save = _lib.bn_forward(x, residual, weight.detach(), bias.detach(), running_mean, running_var, sums, eps, momentum, relu,
+                                  out=out)
+        ctx.grouped = out is not None
+        if out is not None:
+            # y was written into `out` (groups, rows, C) -- a level's block of the flat pyramid, one group per sample; hand
+            # it on as the (samples, cameras, C, h, w) level it is
+            if relu:
+                raise _lib.HipadError("batch_norm_act: grouped output is for the FPN's last norm layer (no ReLU)")
+            n, _, h, w = x.shape
+            y = out.view(out.shape[0], n // out.shape[0], h, w, c).permute(0, 1, 4, 2, 3)
         ctx.save_for_backward(x, y if relu else None, save)
         ctx.weight, ctx.bias, ctx.has_res = weight, bias, residual is not None
         return y
@@ -172,6 +181,8 @@ class _BatchNormAct(Function):
     def backward(ctx, dy):
         x, y, save = ctx.saved_tensors
         weight, bias = ctx.weight, ctx.bias
+        if ctx.grouped:
+            dy = dy.flatten(0, 1)                   # (samples, cameras, C, h, w) -> (N, C, h, w)
         if dy.dtype != x.dtype or not dy.is_contiguous(memory_format=torch.channels_last):
             dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
         rets = [None, None]
@@ -194,7 +205,7 @@ class _BatchNormAct(Function):
             gsums = torch.zeros(_lib.BN_REPLICAS * 2 * x.shape[1] * _lib.BN_SUM_FLOATS, dtype=torch.float32, device=x.device)
         dx, dres = _lib.bn_backward(dy, y, x, save, weight.detach(), gsums, targets[0], targets[1],
                                     ctx.has_res and ctx.needs_input_grad[3])
-        return dx if ctx.needs_input_grad[0] else None, rets[0], rets[1], dres, None, None, None, None, None
+        return dx if ctx.needs_input_grad[0] else None, rets[0], rets[1], dres, None, None, None, None, None, None
 
 
 def batch_norm_act_ok(x, weight):
@@ -204,11 +215,38 @@ def batch_norm_act_ok(x, weight):
             and _lib.bn_supported(x.shape[0] * x.shape[2] * x.shape[3], x.shape[1]))
 
 
-def batch_norm_act(x, weight, bias, running_mean, running_var, eps, momentum, relu=False, residual=None):
+def batch_norm_act(x, weight, bias, running_mean, running_var, eps, momentum, relu=False, residual=None, out=None):
     if residual is not None and (residual.dtype != x.dtype or residual.shape != x.shape
                                  or not residual.is_contiguous(memory_format=torch.channels_last)):
         residual = residual.to(x.dtype).contiguous(memory_format=torch.channels_last)
-    return _BatchNormAct.apply(x, weight, bias, residual, running_mean, running_var, float(eps), float(momentum), bool(relu))
+    return _BatchNormAct.apply(x, weight, bias, residual, running_mean, running_var, float(eps), float(momentum), bool(relu), out)
+
+
+class _FlatPyramid(Function):
+    """The flat pyramid tensor whose blocks the FPN's last norm layers have ALREADY written (batch_norm_act(out=...)):
+    nothing to compute forward -- the node only tells autograd that ``flat`` is made of the levels, and hands each level
+    its block of the flat gradient in the backward (views, no copy)."""
+
+    @staticmethod
+    def forward(ctx, flat, blocks, *levels):
+        ctx.blocks = blocks                               # [(first row, rows per sample)] per level
+        ctx.shapes = [tuple(t.shape) for t in levels]
+        for t, (off, n) in zip(levels, blocks):
+            if t.data_ptr() != flat.data_ptr() + off * flat.shape[2] * flat.element_size():
+                raise _lib.HipadError("flat pyramid: a level is not the block of the flat tensor it claims to be")
+        return flat.view_as(flat)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        outs = []
+        for (off, n), (bs, cams, c, h, w) in zip(ctx.blocks, ctx.shapes):
+            outs.append(g[:, off:off + n].view(bs, cams, h, w, c).permute(0, 1, 4, 2, 3))
+        return (None, None) + tuple(outs)
+
+
+def flat_pyramid(flat, blocks, levels):
+    return _FlatPyramid.apply(flat, blocks, *levels)
 
 
 class _DropoutAdd(Function):

@@ -61,6 +61,8 @@ SIGNATURES = {
     "hipad_chunk_mix": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
     "hipad_bn_supported": (c_int, [ctypes.c_longlong, c_int]),
     "hipad_bn_forward": (c_int, [c_void_p] * 9 + [ctypes.c_longlong, c_int, ctypes.c_float, ctypes.c_float, c_int, c_void_p]),
+    "hipad_bn_forward_grouped": (c_int, [c_void_p] * 9 + [ctypes.c_longlong, c_int, ctypes.c_float, ctypes.c_float, c_int,
+                                         ctypes.c_longlong, ctypes.c_longlong, c_void_p]),
     "hipad_bn_backward": (c_int, [c_void_p] * 10 + [ctypes.c_longlong, c_int, c_void_p]),
     "hipad_grid_mask": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "hipad_dropout_add": (c_int, [c_void_p] * 3 + [ctypes.c_longlong, ctypes.c_float, ctypes.c_uint, c_void_p, c_void_p]),
@@ -608,18 +610,28 @@ def bn_supported(rows, channels):
     return bool(load().hipad_bn_supported(int(rows), int(channels)))
 
 
-def bn_forward(x, residual, gamma, beta, running_mean, running_var, sums, eps, momentum, relu):
+def bn_forward(x, residual, gamma, beta, running_mean, running_var, sums, eps, momentum, relu, out=None):
     """x (N, C, H, W) bf16 channels-last -> (y like x, save (2C,) fp32).  ``sums``: zeroed scratch of BN_REPLICAS * 2C * BN_SUM_FLOATS
-    floats (64-bit fixed-point partial sums, see include/hipad.h)."""
+    floats (64-bit fixed-point partial sums, see include/hipad.h).  ``out``: (groups, rows_per_group, C) bf16 view whose
+    groups may be strided (a level's block inside the flat pyramid, one group per sample): y is written there instead
+    of into a fresh tensor and ``out`` is returned as y."""
     lib = load()
     n, c, h, w = x.shape
     rows = n * h * w
-    y = torch.empty_like(x)           # preserves channels-last
     save = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+    if out is None:
+        y = torch.empty_like(x)           # preserves channels-last
+        group_rows = group_stride = rows
+    else:
+        if out.dtype != x.dtype or out.dim() != 3 or out.shape[2] != c or out.shape[0] * out.shape[1] != rows \
+                or out.stride(2) != 1 or out.stride(1) != c or out.stride(0) % c or out.stride(0) < out.shape[1] * c:
+            raise HipadError(f"bn_forward: out {tuple(out.shape)} / strides {out.stride()} does not hold {rows} rows of {c}")
+        y, group_rows, group_stride = out, out.shape[1], out.stride(0) // c
     with torch.cuda.device(x.device):
-        check(lib.hipad_bn_forward(y.data_ptr(), save.data_ptr(), sums.data_ptr(), x.data_ptr(), _ptr(residual), gamma.data_ptr(),
-                                   beta.data_ptr(), _ptr(running_mean), _ptr(running_var), rows, c, float(eps), float(momentum),
-                                   int(bool(relu)), stream_ptr(x.device)), "hipad_bn_forward")
+        check(lib.hipad_bn_forward_grouped(y.data_ptr(), save.data_ptr(), sums.data_ptr(), x.data_ptr(), _ptr(residual),
+                                           gamma.data_ptr(), beta.data_ptr(), _ptr(running_mean), _ptr(running_var), rows, c,
+                                           float(eps), float(momentum), int(bool(relu)), group_rows, group_stride,
+                                           stream_ptr(x.device)), "hipad_bn_forward")
     return y, save
 
 

@@ -679,6 +679,13 @@ int hipad_bn_supported(long long rows, int channels);
 int hipad_bn_forward(void *y, float *save, float *sums, const void *x, const void *residual, const float *gamma,
                      const float *beta, float *running_mean, float *running_var, long long rows, int channels, float eps,
                      float momentum, int relu, hipad_stream_t stream);
+/* The same with a GROUPED output: output rows [g * y_group_rows, (g + 1) * y_group_rows) are written y_group_stride_rows
+ * rows apart -- the FPN's last norm layer writes each level straight into the flat pyramid the aggregation operator reads
+ * (one group = one sample's block of the level; reference ops/__init__.py:33-103 copies the levels there instead). */
+int hipad_bn_forward_grouped(void *y, float *save, float *sums, const void *x, const void *residual, const float *gamma,
+                             const float *beta, float *running_mean, float *running_var, long long rows, int channels,
+                             float eps, float momentum, int relu, long long y_group_rows, long long y_group_stride_rows,
+                             hipad_stream_t stream);
 int hipad_bn_backward(void *dx, void *dres, float *dgamma, float *dbeta, float *gsums, const void *dy, const void *y,
                       const void *x, const float *save, const float *gamma, long long rows, int channels,
                       hipad_stream_t stream);

@@ -100,9 +100,16 @@ class BatchNorm2d(nn.BatchNorm2d):
     defer_counter = False
     _pending = []
 
-    def forward(self, x, relu=False, residual=None):
+    def fused_path(self, x):
+        """True when ``forward(x)`` runs on the two fused kernels (training statistics, bf16 channels-last, supported width)."""
+        return bool(self.training and self.track_running_stats and self.momentum is not None and self.affine and USE_FUSED_BN
+                    and HF.batch_norm_act_ok(x, self.weight))
+
+    def forward(self, x, relu=False, residual=None, out=None):
         """``relu`` / ``residual`` (ours): relu?(bn(x) (+ residual)) -- on bf16 channels-last training inputs the whole
-        expression is two launches (hipad_bn_forward), two more in the backward; otherwise the torch ops."""
+        expression is two launches (hipad_bn_forward), two more in the backward; otherwise the torch ops.
+        ``out`` (fused path only): (samples, rows, C) block of the flat pyramid the result is written into; the result
+        then comes back as the (samples, cameras, C, h, w) level."""
         deferred = self.defer_counter and self.training and self.track_running_stats and self.momentum is not None
         if (self.training and self.track_running_stats and self.momentum is not None and self.affine and USE_FUSED_BN
                 and HF.batch_norm_act_ok(x, self.weight)):
@@ -111,7 +118,9 @@ class BatchNorm2d(nn.BatchNorm2d):
             else:
                 self.num_batches_tracked.add_(1)
             return HF.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps, self.momentum,
-                                     relu, residual)
+                                     relu, residual, out)
+        if out is not None:
+            raise ValueError("BatchNorm2d: `out` needs the fused path (check fused_path(x) first)")
         if deferred:
             BatchNorm2d._pending.append(self.num_batches_tracked)
             y = nn.functional.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, True,
@@ -247,8 +256,10 @@ class _ConvModule(nn.Module):
             self.bn = BatchNorm2d(cout)
         self.with_bn = with_bn
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         x = self.conv(x)
+        if out is not None:
+            return self.bn(x, out=out)
         return self.bn(x) if self.with_bn else x
 
 
@@ -280,11 +291,19 @@ class FPN(BaseModule):
                 if m.bias is not None:
                     nn.init.constant_(m.bias, 0)
 
-    def forward(self, inputs):
+    def forward(self, inputs, out_blocks=None):
+        """``out_blocks`` (ours): a function (level index, conv output) -> (samples, rows, C) block of the flat pyramid,
+        or None; when every output convolution ends in a norm layer on the fused kernels, that layer writes the level
+        straight into its block and the level comes back as a (samples, cameras, C, h, w) view of the flat tensor."""
         lat = [conv(inputs[i + self.start_level]) for i, conv in enumerate(self.lateral_convs)]
         for i in range(len(lat) - 1, 0, -1):
             lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], size=lat[i - 1].shape[2:], **self.upsample_cfg)
-        return tuple(conv(x) for conv, x in zip(self.fpn_convs, lat))
+        if out_blocks is None or not all(c.with_bn for c in self.fpn_convs):
+            return tuple(conv(x) for conv, x in zip(self.fpn_convs, lat))
+        ys = [conv.conv(x) for conv, x in zip(self.fpn_convs, lat)]
+        if not all(conv.bn.fused_path(y) for conv, y in zip(self.fpn_convs, ys)):
+            return tuple(conv.bn(y) for conv, y in zip(self.fpn_convs, ys))          # (N, C, h, w) levels, as without out_blocks
+        return tuple(conv.bn(y, out=out_blocks(i, y)) for i, (conv, y) in enumerate(zip(self.fpn_convs, ys)))
 
 
 if not HAVE_MMCV:

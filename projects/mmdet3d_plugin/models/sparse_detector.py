@@ -15,7 +15,7 @@ import torch
 from hipad_amd import functional as HF
 from hipad_amd.compat import BACKBONES, DETECTORS, HEADS, NECKS, PLUGIN_LAYERS, BaseModule, build_from_cfg
 
-from ..ops import feature_maps_format, shared_feature_grad
+from ..ops import feature_maps_format, level_major_tables, shared_feature_grad
 from .grid_mask import GridMask
 from .image_encoder import BatchNorm2d as _EncoderBN
 
@@ -25,6 +25,7 @@ __all__ = ["SparseDetector"]
 import os as _os
 
 FLAT_BF16 = _os.environ.get("HIPAD_FLAT_BF16", "1") == "1"   # 0: widen the flat pyramid to fp32 (round-1 behaviour)
+IN_PLACE_PYRAMID = _os.environ.get("HIPAD_IN_PLACE_PYRAMID", "1") == "1"   # 0: copy the levels into the camera-major layout
 
 
 @DETECTORS.register_module()
@@ -72,22 +73,41 @@ class SparseDetector(BaseModule):
         img = img.contiguous(memory_format=torch.channels_last)
         if img.is_cuda and self.training:
             HF.BN_ARENA.reset(img.device)        # one fill clears the partial-sum scratch of all norm layers
+        flat = tables = None
         with torch.autocast("cuda", dtype=self.encoder_dtype, enabled=img.is_cuda and self.encoder_dtype != torch.float32):
             levels = self.img_backbone(img)
             if self.img_neck is not None:
-                levels = self.img_neck(levels)
+                out_blocks = None
+                if (IN_PLACE_PYRAMID and FLAT_BF16 and img.is_cuda and self.training and self.encoder_dtype == torch.bfloat16
+                        and getattr(self.img_neck, "out_channels", None) == 256):
+                    # the FPN's last norm layers write the levels straight into the flat pyramid the decoder reads (level by
+                    # level: a channels-last level IS a block of rows) -- no copy into the "column" layout
+                    hw = [tuple(int(v) for v in t.shape[-2:]) for t in levels[self.img_neck.start_level:self.img_neck.backbone_end_level]]
+                    tables = level_major_tables(hw, num_cams, img.device)
+                    flat = torch.empty(bs, tables[2], 256, dtype=torch.bfloat16, device=img.device)
+                    out_blocks = lambda i, y: flat[:, tables[3][i][0]:tables[3][i][0] + tables[3][i][1]]   # noqa: E731
+                levels = self.img_neck(levels, out_blocks) if out_blocks is not None else self.img_neck(levels)
             _EncoderBN.flush_counters()
+        in_place = flat is not None and all(f.dim() == 5 for f in levels)
         # levels stay in the encoder's dtype (bf16): the depth heads and the flat-layout copy convert on read,
         # so the pyramid is written once in fp32 (as the flat tensor) instead of twice
-        levels = [f.reshape((bs, num_cams) + f.shape[1:]) for f in levels]
+        if not in_place:
+            levels = [f.reshape((bs, num_cams) + f.shape[1:]) for f in levels]
+        else:
+            # an alias node between the norm layer and the level: the eager step's two-part backward takes the gradient AT
+            # the level, and capturing it at a node's own output makes autograd release that node's buffers early
+            levels = [f.view_as(f) for f in levels]
 
         depths = None
         if return_depth and self.depth_branch is not None:
             depths = self.depth_branch(levels, None if metas is None else metas.get("focal"))
         # the flat pyramid keeps the encoder's dtype: bf16 rows go to the aggregation kernels as they are (same values as
         # the reference's fp32 copy of its fp16 pyramid would hold, half the bytes); other widths / dtypes are widened
-        keep = levels[0].dtype == torch.bfloat16 and levels[0].is_cuda and levels[0].shape[2] == 256 and FLAT_BF16
-        feature_maps = feature_maps_format(levels, out_dtype=None if keep else torch.float32)
+        if in_place:
+            feature_maps = [HF.flat_pyramid(flat, tables[3], levels), tables[0], tables[1]]
+        else:
+            keep = levels[0].dtype == torch.bfloat16 and levels[0].is_cuda and levels[0].shape[2] == 256 and FLAT_BF16
+            feature_maps = feature_maps_format(levels, out_dtype=None if keep else torch.float32)
         feature_maps[0] = shared_feature_grad(feature_maps[0])
         # cut point of the eager step's two-part backward (hipad_amd.frame.TrainStep); rides on the flat tensor so that it
         # lives exactly as long as the forward's outputs (a persistent reference on the module kills ROCm 7.2's

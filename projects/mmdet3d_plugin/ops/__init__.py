@@ -16,7 +16,7 @@ import torch
 from .deformable_aggregation import DeformableAggregationFunction, shared_feature_grad
 
 __all__ = ["deformable_aggregation_function", "feature_maps_format", "shared_feature_grad",
-           "DeformableAggregationFunction"]
+           "DeformableAggregationFunction", "level_major_tables"]
 
 
 def deformable_aggregation_function(feature_maps, spatial_shape, scale_start_index, sampling_location, weights):
@@ -52,6 +52,29 @@ def _tables(level_hw, num_cams, device):
 
 
 _tables.cache = {}
+
+
+def level_major_tables(level_hw, num_cams, device):
+    """(spatial_shape, scale_start_index, rows per sample, [(first row, rows)] per level) of a flat pyramid laid out LEVEL
+    by level -- all cameras of level 0, then of level 1, ... -- which is how the encoder's level tensors sit in memory
+    when its last norm layers write them in place (SparseDetector.extract_feat).  The aggregation operator reads
+    positions through (spatial_shape, scale_start_index) only, so any consistent layout serves it; the reference's own
+    ``feature_maps_format`` layout is camera-major (ops/__init__.py:78-96) and stays what ``feature_maps_format`` builds."""
+    key = ("level-major", tuple(level_hw), num_cams, str(device))
+    hit = _tables.cache.get(key)
+    if hit is None:
+        ss = torch.tensor([list(map(list, level_hw))] * num_cams, dtype=torch.int64)
+        blocks, start, off = [], torch.zeros(num_cams, len(level_hw), dtype=torch.int64), 0
+        for l, (h, w) in enumerate(level_hw):
+            blocks.append((off, num_cams * h * w))
+            start[:, l] = off + torch.arange(num_cams) * (h * w)
+            off += num_cams * h * w
+        ss_d, start_d = ss.to(device), start.to(device)
+        ss_d._hipad_host = ss.tolist()
+        ss_d._hipad_i32 = ((ss_d.data_ptr(), ss_d._version), ss_d.int())
+        start_d._hipad_i32 = ((start_d.data_ptr(), start_d._version), start_d.int())
+        hit = _tables.cache[key] = (ss_d, start_d, off, blocks)
+    return hit
 
 
 def _format_one_group(level_maps, out_dtype=None):

@@ -160,15 +160,15 @@ def test_device_entry_refuses_host_tensors():
         P.transform_images(torch.zeros(1, 8, 8, 3, dtype=torch.uint8), dict(resize=1.0))
 
 
-def test_bbox_rotation_equals_reference():
-    from projects.mmdet3d_plugin.datasets.pipelines import BBoxRotation
-    rot = BBoxRotation()
+def test_scene_rotation_equals_reference():
+    """hipad_amd.dataflow.rotate_scene (stacked products on the matrices and the box array) against the reference's
+    BBoxRotation pipeline step on the same sample (fixture from the reference class, make_golden.py)."""
+    from hipad_amd.dataflow import rotate_scene
     for k, ang in enumerate((0.3, -1.1, 0.0)):
-        res = rot(dict(aug_config=dict(rotate_3d=ang), lidar2img=[m.copy() for m in G["lidar2img"]],
-                       lidar2global=G["rot3d_lidar2global"].copy(), gt_bboxes_3d=G["rot3d_boxes"].copy()))
-        assert np.allclose(np.stack(res["lidar2img"]), G[f"rot3d_{k}_lidar2img"], rtol=1e-12, atol=1e-12)
-        assert np.allclose(res["lidar2global"], G[f"rot3d_{k}_lidar2global"], rtol=1e-12, atol=1e-12)
-        assert np.allclose(res["gt_bboxes_3d"], G[f"rot3d_{k}_boxes"], rtol=1e-12, atol=1e-12)
+        mats, pose, boxes = rotate_scene(np.stack(G["lidar2img"]), G["rot3d_lidar2global"], G["rot3d_boxes"], ang)
+        assert np.allclose(mats, G[f"rot3d_{k}_lidar2img"], rtol=1e-12, atol=1e-12)
+        assert np.allclose(pose, G[f"rot3d_{k}_lidar2global"], rtol=1e-12, atol=1e-12)
+        assert np.allclose(boxes, G[f"rot3d_{k}_boxes"], rtol=1e-12, atol=1e-12)
 
 
 def test_adaptor_step_equals_reference():

