@@ -364,7 +364,7 @@ def _daf_grid_threads(A, P, cams=6, bs=1):
     return ((n_anchor * nchunks + 3) // 4) * 256
 
 
-PMC_FILE = "r02y_daf_pmc_traffic.json"
+PMC_FILE = "r03_daf_pmc_traffic.json"
 MFMA_PMC_FILE = "r02a_linear_path_mfma_pmc.json"
 
 

@@ -301,27 +301,57 @@ __global__ __launch_bounds__(1024) void daf_alloc_kernel(int *__restrict__ cnt,
 // ------------------------------------------------------------------------------------------
 // 4: grad_feat from row-sorted taps.  C == 256, G == 8.  Persistent grid-stride over batches.
 // ------------------------------------------------------------------------------------------
+// consecutive 64-tap batches one wave walks with its row sum carried along (hipad_daf_set_feat_run overrides)
+static int g_feat_run = 4;
+void daf_set_feat_run(int batches) { g_feat_run = batches > 0 && batches <= 64 ? batches : 4; }
+
 __global__ __launch_bounds__(256) void daf_bwd_feat_kernel(
     float *__restrict__ gfeat, const int *__restrict__ taps, const int *__restrict__ offs,
     const int *__restrict__ ends /* cursor after placement */, const int *__restrict__ total_p,
     const MultiArgs margs, const int *__restrict__ ss,
-    const int *__restrict__ start, int R, int cams, int num_feat, int L, int npairL) {
+    const int *__restrict__ start, int R, int cams, int num_feat, int L, int npairL, int kFeatRun) {
   __shared__ float wc_s[4][kWave][8];
   __shared__ int htab[4][256];  // per wave: lowest lane of every hash bucket of (row, grad_out row) keys
+  __shared__ float tr_s[4][256];  // per wave: one row's partial sums on their way to contiguous atomics
   __shared__ MultiArgs m;
   const int lane = threadIdx.x & (kWave - 1);
   const int wv = threadIdx.x >> 6;
   stage_calls(m, margs);
   __syncthreads();
   const int total = min(max(*total_p, 0), npairL * 4);  // never past the tap buffer, whatever the counter says
-  const int nbatch = (total + kWave - 1) / kWave;
+  const int nrun = (total + kFeatRun * kWave - 1) / (kFeatRun * kWave);
   const int nwaves = gridDim.x * 4;
   const int g = lane >> 3;  // group of this lane's 4 channels
   float4 *gfeat4 = reinterpret_cast<float4 *>(gfeat);
 
-  for (int batch = uni(blockIdx.x * 4 + wv); batch < nbatch; batch += nwaves) {
-    const int t0 = batch * kWave;
-    const int n = min(kWave, total - t0);
+  // A row whose taps all lie inside the wave's run is written with one plain read-modify-write; the (at most two) rows
+  // a run shares with its neighbours are added with atomics.  The atomics execute at the memory side (the neighbour's
+  // workgroup sits on another XCD), so they are issued on CONTIGUOUS addresses: the lane's four channels go through
+  // LDS and every atomic instruction of the wave covers 256 consecutive bytes.  With one lane adding floats 16 bytes
+  // apart the write counter (profiles/r03_daf_pmc_traffic.json) showed 584 MB per frame for 51 MB of touched rows.
+  auto flush = [&](int r, int ex, const float4 &o, const float4 &a4) {
+    if (r < 0) return;
+    if (ex) {
+      gfeat4[(size_t)r * 64 + lane] = make_float4(o.x + a4.x, o.y + a4.y, o.z + a4.z, o.w + a4.w);
+    } else {
+      reinterpret_cast<float4 *>(&tr_s[wv][0])[lane] = a4;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      float *pf = gfeat + (size_t)r * 256 + lane;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) atomicAdd(pf + k * kWave, tr_s[wv][k * kWave + lane]);
+      __builtin_amdgcn_wave_barrier();
+    }
+  };
+
+  for (int run = uni(blockIdx.x * 4 + wv); run < nrun; run += nwaves) {
+   const int r0 = run * (kFeatRun * kWave);
+   const int r1 = min(total, r0 + kFeatRun * kWave);
+   int cur = -1, cur_excl = 0;
+   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+   float4 old = make_float4(0.f, 0.f, 0.f, 0.f);
+   for (int t0 = r0; t0 < r1; t0 += kWave) {
+    const int n = min(kWave, r1 - t0);
     // ---- parallel decode: lane <-> tap
     int row = -1, excl = 0;
     // grad_out row of the tap's anchor (a 64-bit address in two lanes' registers: the calls' grad_out tensors are
@@ -356,7 +386,7 @@ __global__ __launch_bounds__(256) void daf_bwd_feat_kernel(
       const float4 wa = w4[0], wb = w4[1];
       wq[0] = coef * wa.x; wq[1] = coef * wa.y; wq[2] = coef * wa.z; wq[3] = coef * wa.w;
       wq[4] = coef * wb.x; wq[5] = coef * wb.y; wq[6] = coef * wb.z; wq[7] = coef * wb.w;
-      excl = (offs[row] >= t0 && ends[row] <= t0 + kWave) ? 1 : 0;
+      excl = (offs[row] >= r0 && ends[row] <= r1) ? 1 : 0;
     }
     __builtin_amdgcn_wave_barrier();
     reinterpret_cast<float4 *>(&wc_s[wv][lane][0])[0] = make_float4(wq[0], wq[1], wq[2], wq[3]);
@@ -386,19 +416,6 @@ __global__ __launch_bounds__(256) void daf_bwd_feat_kernel(
     unsigned long long live = __ballot(row >= 0 && leader == lane);
 
     // ---- walk the leaders (rows ascend with the lane index: a merged tap belongs to its leader's row)
-    auto flush = [&](int r, int ex, const float4 &o, const float4 &a4) {
-      if (r < 0) return;
-      float4 *p = gfeat4 + (size_t)r * 64 + lane;
-      if (ex) {
-        *p = make_float4(o.x + a4.x, o.y + a4.y, o.z + a4.z, o.w + a4.w);
-      } else {
-        float *pf = reinterpret_cast<float *>(p);
-        atomicAdd(pf + 0, a4.x); atomicAdd(pf + 1, a4.y); atomicAdd(pf + 2, a4.z); atomicAdd(pf + 3, a4.w);
-      }
-    };
-    int cur = -1, cur_excl = 0;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 old = make_float4(0.f, 0.f, 0.f, 0.f);
     // kAhead grad_out rows in flight: with one load per iteration behind the row-change branch every tap paid a full
     // memory latency.  The row's present value is fetched when the row starts and wanted only when it ends.
     // Measured on the frame pass (tools/sweep_tap_chunks.py): 4 ahead 830 us, 8 ahead 870 (the last trip of a batch
@@ -441,8 +458,9 @@ __global__ __launch_bounds__(256) void daf_bwd_feat_kernel(
       }
       live = mm;
     }
-    flush(cur, cur_excl, old, acc);
     __builtin_amdgcn_wave_barrier();  // wc_s[wv] / htab[wv] are rewritten by the next batch
+   }
+   flush(cur, cur_excl, old, acc);
   }
 }
 
@@ -656,11 +674,12 @@ static int run_sorted(const MultiArgs &m, const int *ss, const int *start, float
                      num_feat, L, cap, nch);
   // persistent grid: up to 2048 blocks x 4 waves walk the batches of 64 taps
   const long long tmax = (long long)npair * L * 4;
-  long long nb = (tmax + 255) / 256;
+  const int kFeatRun = g_feat_run;
+  long long nb = (tmax + 256 * kFeatRun - 1) / (256 * kFeatRun);
   if (nb > 2048) nb = 2048;
   hipLaunchKernelGGL(daf_bwd_feat_kernel, dim3((unsigned)nb), dim3(256), 0, stream, gfeat, (const int *)w.taps,
                      (const int *)w.offs, (const int *)w.cursor, (const int *)(w.cnt + R), m, ss, start, R, cams, num_feat,
-                     L, npair * L);
+                     L, npair * L, kFeatRun);
   return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
 }
 
@@ -702,6 +721,7 @@ static int multi_table(MultiArgs &m, const hipad_daf_call *calls, int ncalls, in
 extern "C" {
 
 void hipad_daf_set_tap_chunks(int chunks) { hipad::daf_set_tap_chunks(chunks); }
+void hipad_daf_set_feat_run(int batches) { hipad::daf_set_feat_run(batches); }
 
 size_t hipad_daf_backward_feat_multi_workspace(const hipad_daf_call *calls, int ncalls, int bs, int cams, int num_feat,
                                                int C, int L, int G) {

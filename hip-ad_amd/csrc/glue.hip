@@ -172,6 +172,24 @@ __global__ __launch_bounds__(256) void grid_mask_kernel(void *__restrict__ out, 
   }
 }
 
+// Way-points -> per-step offsets of a trajectory (rows of T steps x D coordinates): out[t] = x[t] - x[t-1], out[0] =
+// x[0] (the planning head's output format, reference models/sparse_onedecoder.py refine step of the plan branch:
+// cat(wp[:1], wp[1:] - wp[:-1])); adjoint = 1 applies the transposed map to a gradient: out[t] = g[t] - g[t+1],
+// out[T-1] = g[T-1].
+__global__ __launch_bounds__(256) void step_offsets_kernel(float *__restrict__ out, const float *__restrict__ x, long n,
+                                                           int T, int D, int adjoint) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int t = (int)((i / D) % T);
+  float v = x[i];
+  if (adjoint) {
+    if (t + 1 < T) v -= x[i + D];
+  } else {
+    if (t > 0) v -= x[i - D];
+  }
+  out[i] = v;
+}
+
 }  // namespace hipad
 
 using namespace hipad;
@@ -234,6 +252,15 @@ int hipad_motion_query_embed(float *out, const float *cls, const float *box, con
   if (total >= (1l << 40)) return HIPAD_ERANGE;
   hipLaunchKernelGGL(motion_embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out,
                      cls, box, table, freq, (long)n_anchor, num_classes, box_dim, sin_col, cos_col, modes, steps, half_dim);
+  return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
+}
+
+int hipad_step_offsets(float *out, const float *x, long long rows, int steps, int dims, int adjoint, hipad_stream_t stream) {
+  if (!out || !x || out == x || rows <= 0 || steps <= 0 || dims <= 0) return HIPAD_EINVAL;
+  const long n = (long)rows * steps * dims;
+  if (n >= (1l << 40)) return HIPAD_ERANGE;
+  hipLaunchKernelGGL(step_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, x, n,
+                     steps, dims, adjoint ? 1 : 0);
   return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
 }
 

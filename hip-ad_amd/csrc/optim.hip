@@ -17,6 +17,7 @@
 //                   (incremented here), so the whole thing replays from a hipGraph.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "hipad.h"
 
@@ -207,6 +208,48 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(unsigned short *const
   }
 }
 
+// dst[k] (fp32, contiguous) += src[k] (bf16, 4-D with element strides) for up to HIPAD_ACC_MAX tensors in ONE launch: the
+// table travels by value in the kernel arguments (safe under hipGraph capture: no upload).  1024 elements per workgroup.
+struct AccTable {
+  float *dst[HIPAD_ACC_MAX];
+  const unsigned short *src[HIPAD_ACC_MAX];
+  int dims[HIPAD_ACC_MAX][3];      // sizes of dims 1..3 (dim 0 follows from the element count)
+  int strides[HIPAD_ACC_MAX][4];   // source element strides
+  int numel[HIPAD_ACC_MAX];
+  int block_start[HIPAD_ACC_MAX + 1];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void accumulate_bf16_kernel(const AccTable t) {
+  __shared__ int bs_s[HIPAD_ACC_MAX + 1];
+  for (int i = threadIdx.x; i <= t.n; i += blockDim.x) bs_s[i] = t.block_start[i];
+  __syncthreads();
+  const int b = blockIdx.x;
+  int lo = 0, hi = t.n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (bs_s[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  const int k = lo;
+  const int d1 = t.dims[k][0], d2 = t.dims[k][1], d3 = t.dims[k][2];
+  const int s0 = t.strides[k][0], s1 = t.strides[k][1], s2 = t.strides[k][2], s3 = t.strides[k][3];
+  float *dst = t.dst[k];
+  const unsigned short *src = t.src[k];
+  const int n = t.numel[k];
+  const int base = (b - bs_s[k]) * 1024;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = base + j * 256 + threadIdx.x;
+    if (i < n) {
+      const int i3 = i % d3, r3 = i / d3;
+      const int i2 = r3 % d2, r2 = r3 / d2;
+      const int i1 = r2 % d1, i0 = r2 / d1;
+      const unsigned short v = src[(long)i0 * s0 + (long)i1 * s1 + (long)i2 * s2 + (long)i3 * s3];
+      dst[i] += __uint_as_float((unsigned)v << 16);
+    }
+  }
+}
+
 }  // namespace hipad
 
 using namespace hipad;
@@ -250,6 +293,36 @@ int hipad_adamw_step(float *param, float *grad, float *exp_avg, float *exp_avg_s
   hipLaunchKernelGGL(adamw_flat_kernel, dim3(2048), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, (long)n,
                      (long)n_group0, (const float *)partial, step_dev, norm_out_dev, shadow_bf16, k, zero_grad);
   hipLaunchKernelGGL(adamw_bump_kernel, dim3(1), dim3(1), 0, stream, step_dev);
+  return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
+}
+
+int hipad_accumulate_bf16(const hipad_acc_item *items, int n_items, hipad_stream_t stream) {
+  if (!items || n_items <= 0 || n_items > HIPAD_ACC_MAX) return HIPAD_EINVAL;
+  AccTable t;
+  memset(&t, 0, sizeof(t));
+  long long blocks = 0;
+  for (int k = 0; k < n_items; ++k) {
+    const hipad_acc_item &it = items[k];
+    if (!it.dst || !it.src) return HIPAD_EINVAL;
+    long long numel = 1;
+    for (int d = 0; d < 4; ++d) {
+      if (it.sizes[d] <= 0 || it.strides[d] < 0) return HIPAD_EINVAL;
+      numel *= it.sizes[d];
+      if (numel > 0x7fffffffll || (long long)(it.sizes[d] - 1) * it.strides[d] > 0x7fffffffll) return HIPAD_ERANGE;
+    }
+    if (((uintptr_t)it.dst & 3) || ((uintptr_t)it.src & 1)) return HIPAD_EINVAL;
+    t.dst[k] = it.dst;
+    t.src[k] = it.src;
+    for (int d = 0; d < 3; ++d) t.dims[k][d] = it.sizes[d + 1];
+    for (int d = 0; d < 4; ++d) t.strides[k][d] = it.strides[d];
+    t.numel[k] = (int)numel;
+    t.block_start[k] = (int)blocks;
+    blocks += (numel + 1023) / 1024;
+    if (blocks > 0x7fffffffll) return HIPAD_ERANGE;
+  }
+  t.block_start[n_items] = (int)blocks;
+  t.n = n_items;
+  hipLaunchKernelGGL(accumulate_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t);
   return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
 }
 

@@ -573,6 +573,25 @@ def focal_loss(logits, target, weight=None, avg_factor=None, layers=1, alpha=0.2
     return _FocalLoss.apply(logits, target, weight, avg_factor, int(layers), float(alpha), float(gamma))
 
 
+class _StepOffsets(Function):
+    @staticmethod
+    def forward(ctx, x):
+        return _lib.step_offsets(_c32(x))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        return _lib.step_offsets(_c32(gout), adjoint=True)
+
+
+def step_offsets(x):
+    """(..., steps, dims) way-points -> offsets between consecutive steps (the first step keeps its value): one launch
+    forward, one backward (include/hipad.h: hipad_step_offsets).  CPU tensors: the torch expression."""
+    if not x.is_cuda:
+        return torch.cat([x[..., :1, :], x[..., 1:, :] - x[..., :-1, :]], dim=-2)
+    return _StepOffsets.apply(x)
+
+
 class _ChunkMix(Function):
     @staticmethod
     def forward(ctx, x0, x1, table, rows):

@@ -26,6 +26,7 @@ SIGNATURES = {
     "hipad_daf_backward": (c_int, [c_void_p] * 9 + [c_int] * 8 + [c_int, c_void_p, c_size_t, c_void_p]),
     "hipad_daf_taps": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
     "hipad_daf_set_tap_chunks": (None, [c_int]),
+    "hipad_daf_set_feat_run": (None, [c_int]),
     "hipad_daf_backward_feat_multi_workspace": (c_size_t, [c_void_p, c_int] + [c_int] * 6),
     "hipad_daf_backward_feat_multi": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 6
                                       + [c_void_p, c_size_t, c_void_p]),
@@ -72,6 +73,8 @@ SIGNATURES = {
     "hipad_image_finish": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                                                       c_void_p]),
     "hipad_motion_query_embed": (c_int, [c_void_p] * 5 + [ctypes.c_longlong] + [c_int] * 7 + [c_void_p]),
+    "hipad_accumulate_bf16": (c_int, [c_void_p, c_int, c_void_p]),
+    "hipad_step_offsets": (c_int, [c_void_p] * 2 + [ctypes.c_longlong] + [c_int] * 3 + [c_void_p]),
     "hipad_chain_forward": (c_int, [c_void_p, c_int, c_void_p]),
     "hipad_chain_debug_stamps": (None, [c_void_p]),
     "hipad_chain_backward_dx": (c_int, [c_void_p, c_int, c_void_p]),
@@ -715,6 +718,54 @@ def motion_query_embed(cls, box, table, freq, sin_col, cos_col):
         check(lib.hipad_motion_query_embed(out.data_ptr(), cls.data_ptr(), box.data_ptr(), table.data_ptr(), freq.data_ptr(),
                                            bs * A, ncls, D, sin_col, cos_col, modes, ts, half, stream_ptr(cls.device)),
               "hipad_motion_query_embed")
+    return out
+
+
+class AccItem(ctypes.Structure):
+    _fields_ = [("dst", c_void_p), ("src", c_void_p), ("sizes", ctypes.c_int32 * 4), ("strides", ctypes.c_int32 * 4)]
+
+
+ACC_MAX = 64
+
+
+def accumulate_bf16(pairs):
+    """``pairs``: [(dst fp32 contiguous, src bf16 of the same shape, any strides, <= 4-D)]: dst += src, 64 tensors a launch."""
+    lib = load()
+    if not pairs:
+        return
+    dev = pairs[0][0].device
+    items = []
+    for dst, src in pairs:
+        _req(dst, torch.float32, "dst")
+        if not src.is_cuda or src.dtype != torch.bfloat16 or src.device != dev or dst.device != dev:
+            raise HipadError("accumulate_bf16: src must be a bf16 tensor on dst's device")
+        if src.shape != dst.shape or src.dim() > 4 or src.numel() == 0:
+            raise HipadError(f"accumulate_bf16: shapes {tuple(dst.shape)} / {tuple(src.shape)} (need equal, <= 4-D, non-empty)")
+        pad = 4 - src.dim()
+        it = AccItem()
+        it.dst, it.src = dst.data_ptr(), src.data_ptr()
+        for d in range(4):
+            it.sizes[d] = 1 if d < pad else src.shape[d - pad]
+            it.strides[d] = 0 if d < pad else src.stride(d - pad)
+        items.append(it)
+    with torch.cuda.device(dev):
+        for i in range(0, len(items), ACC_MAX):
+            chunk = items[i:i + ACC_MAX]
+            arr = (AccItem * len(chunk))(*chunk)
+            check(lib.hipad_accumulate_bf16(arr, len(chunk), stream_ptr(dev)), "hipad_accumulate_bf16")
+
+
+def step_offsets(x, adjoint=False):
+    """(..., steps, dims) way-points -> per-step offsets along the second-to-last axis (adjoint: the transposed map)."""
+    lib = load()
+    _req(x, torch.float32, "x")
+    if x.dim() < 2 or x.numel() == 0:
+        raise HipadError("step_offsets: x must be (..., steps, dims), non-empty")
+    steps, dims = x.shape[-2], x.shape[-1]
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(lib.hipad_step_offsets(out.data_ptr(), x.data_ptr(), x.numel() // (steps * dims), steps, dims,
+                                     1 if adjoint else 0, stream_ptr(x.device)), "hipad_step_offsets")
     return out
 
 

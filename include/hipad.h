@@ -149,6 +149,9 @@ typedef struct hipad_daf_call {
 /* Tuning knob of the counting sort (like hipad_daf_set_pairs_per_wave): chunks of 1024 (anchor, point) indices one
  * workgroup of the tap passes walks; 0 = automatic (about one workgroup per CU). */
 void hipad_daf_set_tap_chunks(int chunks);
+/* Tuning knob of the accumulation pass: consecutive batches of 64 sorted taps one wave walks with its row sum carried
+ * along (rows inside a run are written without atomics); 1..64, anything else = the default (4). */
+void hipad_daf_set_feat_run(int batches);
 
 size_t hipad_daf_backward_feat_multi_workspace(const hipad_daf_call *calls, int ncalls, int batch_size, int num_cams,
                                                int num_feat, int num_embeds, int num_scale, int num_groups);
@@ -497,6 +500,20 @@ typedef struct hipad_lr_schedule {
 size_t hipad_adamw_workspace(void);
 float hipad_lr_factor(const hipad_lr_schedule *sched, int iteration);
 int hipad_shadow_bf16(unsigned short *dst, const float *src, long long n, hipad_stream_t stream);
+
+/* hipad_accumulate_bf16: dst[k] += src[k] for up to HIPAD_ACC_MAX tensors in one launch.  Replaces: the per-layer
+ *   `weight.grad.add_(bf16 weight gradient)` of the image encoder's convolutions under bf16 autocast (torch: the cast back
+ *   to fp32 in ToCopyBackward + AccumulateGrad, one or two launches per convolution, ~60 convolutions per frame).
+ *   dst: fp32, contiguous, sizes[0..3]; src: bf16 with ELEMENT strides[0..3] (channels-last weight gradients are read in
+ *   place).  items: HOST array (the table is passed in the kernel arguments: nothing to upload, capturable). */
+#define HIPAD_ACC_MAX 64
+typedef struct hipad_acc_item {
+  float *dst;
+  const unsigned short *src;
+  int32_t sizes[4];
+  int32_t strides[4];
+} hipad_acc_item;
+int hipad_accumulate_bf16(const hipad_acc_item *items, int n_items, hipad_stream_t stream);
 int hipad_adamw_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, long long n,
                      long long n_group0, float lr0, float lr1, float beta1, float beta2, float eps,
                      float weight_decay, float max_norm, int *step_dev, float *norm_out_dev,
@@ -596,6 +613,11 @@ int hipad_pack_weights(unsigned short *const *dst, unsigned short *const *dst_t,
  *   cls (n_anchor, num_classes) logits; box (n_anchor, box_dim); table (num_classes, modes, steps, 2);
  *   freq (half_dim) = 10000 ** (2 * (k / 2) / half_dim); out (n_anchor, modes, 2 * half_dim) = [embed(y) | embed(x)],
  *   embed(v)[k] = sin or cos (k odd) of v * 2 pi / freq[k], same operation order as the torch expression.
+ * hipad_step_offsets.  Replaces: the planning branch's way-points -> per-step offsets (reference
+ *   models/sparse_onedecoder.py, plan refinement: cat(wp[:1], wp[1:] - wp[:-1]) along the time axis; slice / subtract /
+ *   concatenate launches forward, their slice-backward fills and joins backward).  x, out: (rows, steps, dims) fp32,
+ *   out != x; out[t] = x[t] - x[t-1], out[0] = x[0]; adjoint != 0 applies the transposed map (a gradient's backward):
+ *   out[t] = x[t] - x[t+1], out[steps-1] = x[steps-1].
  * hipad_keep_mask.  Replaces: the Bernoulli keep mask of DeformableFeatureAggregation's attn_drop (reference
  *   models/blocks.py:209-212; rand, compare, cast, rescale = four launches): out[i] = 1 / (1 - p_drop) with probability
  *   1 - p_drop else 0, drawn from (seed, *seed_dev, i) -- seed_dev (may be NULL) is a device step counter, so a replayed
@@ -620,6 +642,7 @@ int hipad_chunk_mix(float *out, const float *x0, const float *x1, const float *w
 int hipad_motion_query_embed(float *out, const float *cls, const float *box, const float *table, const float *freq,
                              long long n_anchor, int num_classes, int box_dim, int sin_col, int cos_col, int modes,
                              int steps, int half_dim, hipad_stream_t stream);
+int hipad_step_offsets(float *out, const float *x, long long rows, int steps, int dims, int adjoint, hipad_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Image leg of the training data pipeline (hip-ad_amd/csrc/imgpipe.hip).  Replaces, for all camera images of one

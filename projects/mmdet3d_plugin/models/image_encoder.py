@@ -64,10 +64,37 @@ class _ShadowWeight(torch.autograd.Function):
         w = ctx.weight
         tgt = w.grad if (HF.LINEAR_INPLACE_GRAD and w.is_leaf) else None
         if tgt is not None and tgt.dtype == torch.float32 and tgt.is_contiguous():
-            tgt.add_(g)
             HF.INPLACE_PARAMS.add(id(w))
+            if BATCH_WEIGHT_GRADS and g.is_cuda and g.dtype == torch.bfloat16 and g.dim() <= 4:
+                # all convolutions' gradients of this backward pass go into their fp32 buffers in ONE launch when the
+                # pass ends (engine callback), instead of one add per layer
+                task = torch._C._current_graph_task_id()
+                if _PASS[0] != task:            # first convolution of this backward pass
+                    _PASS[0] = task
+                    _PENDING.clear()            # (leftovers of a pass that ended in an exception)
+                    torch.autograd.Variable._execution_engine.queue_callback(_flush_weight_grads)
+                _PENDING.append((tgt, g))
+            else:
+                tgt.add_(g)
             return None, None
         return g.to(w.dtype), None
+
+
+BATCH_WEIGHT_GRADS = _os.environ.get("HIPAD_BATCH_WEIGHT_GRADS", "1") == "1"
+_PENDING = []
+_PASS = [None]
+
+
+def _flush_weight_grads():
+    from hipad_amd import lib as _lib
+    pairs = list(_PENDING)
+    _PENDING.clear()
+    _PASS[0] = None
+    by_dev = {}
+    for tgt, g in pairs:
+        by_dev.setdefault(tgt.device, []).append((tgt, g))
+    for dev_pairs in by_dev.values():
+        _lib.accumulate_bf16(dev_pairs)
 
 
 class Conv2d(nn.Conv2d):

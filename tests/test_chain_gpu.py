@@ -272,6 +272,26 @@ def test_chunk_mix_and_motion_embedding_match_torch():
     assert float((got - want).abs().max()) < 2e-3 and float((got - want).abs().mean()) < 1e-5
 
 
+def test_step_offsets_match_the_slice_and_concatenate_expression():
+    """Way-points -> offsets (plan branch): bit-equal to the torch expression, forward and backward."""
+    from hipad_amd import functional as HF
+    from hipad_amd import lib
+    g = torch.Generator().manual_seed(9)
+    for shape in [(2, 1, 48, 6, 2), (1, 5, 1, 3), (3, 7, 1)]:
+        x = torch.randn(*shape, generator=g).cuda().requires_grad_(True)
+        out = HF.step_offsets(x)
+        go = torch.randn(shape, generator=g).cuda()
+        out.backward(go)
+        y = x.detach().cpu().requires_grad_(True)
+        ref = HF.step_offsets(y)                  # CPU branch: cat(x[:1], x[1:] - x[:-1])
+        ref.backward(go.cpu())
+        assert torch.equal(out.cpu(), ref) and torch.equal(x.grad.cpu(), y.grad)
+    with pytest.raises(lib.HipadError):
+        lib.step_offsets(torch.zeros(4, device="cuda"))
+    with pytest.raises(lib.HipadError):
+        lib.step_offsets(torch.zeros(2, 3, 2, device="cuda", dtype=torch.float64))
+
+
 def test_keep_mask_statistics_and_clock():
     from hipad_amd import functional as HF
     from hipad_amd import lib

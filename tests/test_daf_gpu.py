@@ -349,3 +349,22 @@ def test_feat_multi_through_the_autograd_sink(lib, monkeypatch):
     assert rel_err(grads[True][0], grads[False][0].cpu().numpy()) < 1e-2      # bf16 leaf gradient: one rounding apart
     for a, b in zip(grads[True][1:], grads[False][1:]):
         assert torch.equal(a, b)                                             # grad_loc / grad_w: the same kernel
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("run", [1, 2, 3, 16, 64])
+def test_feat_multi_is_the_same_for_every_run_length(lib, run):
+    """hipad_daf_set_feat_run only moves the boundaries between plain and atomic row updates: every run length gives
+    the oracle's feature gradient (a run of 64 batches covers this whole case in a handful of waves)."""
+    feat, ss, st, calls = _multi_calls(2, [(37, 13), (5, 300), (9, 90), (1, 13)])
+    ref = np.zeros(feat.shape, np.float64)
+    for loc, w, gout in calls:
+        ref += O.daf_backward(feat.numpy(), ss, st, loc.numpy(), w.numpy(), gout.numpy(), acc64=True)[0]
+    gf = torch.zeros(feat.shape, device="cuda")
+    try:
+        lib.load().hipad_daf_set_feat_run(run)
+        lib.daf_backward_feat_multi([tuple(t.cuda() for t in c) for c in calls], gf, torch.from_numpy(ss).cuda(),
+                                    torch.from_numpy(st).cuda())
+    finally:
+        lib.load().hipad_daf_set_feat_run(0)
+    assert rel_err(gf, ref) < 1e-5

@@ -129,3 +129,51 @@ def test_bf16_copies_follow_a_checkpoint_load():
     w.data = w.data.clone()
     with pytest.raises(RuntimeError):
         CH.bf16_pair(w)
+
+
+def test_accumulate_bf16_adds_every_layout_in_one_launch():
+    """hipad_accumulate_bf16: dst += src for contiguous, channels-last and lower-rank bf16 sources, more tensors than
+    one table holds; equal to torch's add_ (one bf16 -> fp32 widening, one fp32 add: bit-exact)."""
+    from hipad_amd import lib
+    g = torch.Generator().manual_seed(4)
+    shapes = [(64, 3, 7, 7), (256, 64, 1, 1), (64, 64, 3, 3), (5,), (7, 3), (2, 3, 4)] * 12      # 72 > HIPAD_ACC_MAX
+    pairs, want = [], []
+    for i, s in enumerate(shapes):
+        dst = torch.randn(*s, generator=g).cuda()
+        src = torch.randn(*s, generator=g).cuda().to(torch.bfloat16)
+        if len(s) == 4 and i % 2 == 0:
+            src = src.contiguous(memory_format=torch.channels_last)
+        want.append(dst + src.float())
+        pairs.append((dst, src))
+    assert len(pairs) > lib.ACC_MAX
+    lib.accumulate_bf16(pairs)
+    for (dst, _), w in zip(pairs, want):
+        assert torch.equal(dst, w)
+    with pytest.raises(lib.HipadError):
+        lib.accumulate_bf16([(torch.zeros(3, device="cuda"), torch.zeros(4, device="cuda", dtype=torch.bfloat16))])
+    with pytest.raises(lib.HipadError):
+        lib.accumulate_bf16([(torch.zeros(3, device="cuda"), torch.zeros(3, device="cuda"))])
+
+
+def test_convolution_weight_gradients_arrive_batched(monkeypatch):
+    """The encoder's convolutions under bf16 autocast with optimiser-kept bf16 weights: all weight gradients of one
+    backward pass are added into the fp32 .grad buffers by one engine callback -- same numbers as one add per layer."""
+    from projects.mmdet3d_plugin.models import image_encoder as IE
+    from hipad_amd import functional as HF
+    g = torch.Generator().manual_seed(6)
+    convs = [IE.Conv2d(8, 16, 3, padding=1, bias=False).cuda(), IE.Conv2d(16, 16, 1, bias=False).cuda()]
+    for c in convs:
+        c.weight._hipad_bf16 = c.weight.detach().to(torch.bfloat16).reshape(-1)
+    x = torch.randn(2, 8, 12, 12, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    res = {}
+    for batched in (True, False):
+        monkeypatch.setattr(IE, "BATCH_WEIGHT_GRADS", batched)
+        for c in convs:
+            c.weight.grad = torch.full_like(c.weight, 0.5)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = convs[1](convs[0](x))
+        y.float().square().sum().backward()
+        assert not IE._PENDING
+        res[batched] = [c.weight.grad.clone() for c in convs]
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b) and float((a - 0.5).abs().max()) > 0

@@ -13,6 +13,6 @@ NSTEPS=${NSTEPS:-8} rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_$t
 cd "$root"
 python tools/trace_categories.py /tmp/prof_$tag steps 3 > "$out/categories.txt"
 python tools/trace_counts.py /tmp/prof_$tag steps 3 90 > "$out/launch_counts.txt"
-python tools/trace_summary.py /tmp/prof_$tag 400 | grep -i "daf\|hipad\|chain\|gemm\|attn\|^kernel" > "$out/kernels_by_grid.txt"
+python tools/trace_summary.py /tmp/prof_$tag 160 > "$out/kernels_by_grid.txt" 2> "$out/kernels_by_grid.err"
 grep -v "^W2\|^E2" "$out/graph_frame_traced.log" | tail -4
 cat "$out/categories.txt"

@@ -7,12 +7,12 @@ import sys
 
 path = sys.argv[1]
 if os.path.isdir(path):
-    path = glob.glob(path + "/**/*kernel_trace.csv", recursive=True)[0]
+    path = max(glob.glob(path + "/**/*kernel_trace.csv", recursive=True), key=os.path.getsize)   # the traced program, not a helper process
 rows = list(csv.DictReader(open(path)))
 agg = collections.defaultdict(list)
 for r in rows:
     name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("hipad::", "")
-    agg[(name[-40:], "%sx%sx%s" % (int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])), r["Grid_Size_Y"], r["Grid_Size_Z"]), r["VGPR_Count"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    agg[(name[:40], "%sx%sx%s" % (int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])), r["Grid_Size_Y"], r["Grid_Size_Z"]), r["VGPR_Count"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 print(f"{'kernel':42s} {'grid':>12s} {'vgpr':>5s} {'n':>5s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s}")
 for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:top]:
