@@ -190,6 +190,54 @@ __global__ __launch_bounds__(256) void step_offsets_kernel(float *__restrict__ o
   out[i] = v;
 }
 
+// out[b, r, :] = base[b, r, :] + sum_k rows_k[b, :]  (up to three row vectors broadcast over the N rows of a sample): the
+// planning branch's `embed + target-point embed + command embed + ego embed` and `feature + ego feature` (reference
+// models/sparse_onedecoder.py, plan refinement), one launch instead of one per addend.  float4 per thread.
+__global__ __launch_bounds__(256) void add_rows_kernel(float *__restrict__ out, const float *__restrict__ base,
+                                                       const float *__restrict__ r0, const float *__restrict__ r1,
+                                                       const float *__restrict__ r2, long n4, int N, int C4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const long row = i / C4;
+  const int c = (int)(i - row * C4);
+  const long b = row / N;
+  float4 v = reinterpret_cast<const float4 *>(base)[i];
+  const float *rs[3] = {r0, r1, r2};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (rs[k]) {
+      const float4 a = reinterpret_cast<const float4 *>(rs[k])[b * C4 + c];
+      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+  }
+  reinterpret_cast<float4 *>(out)[i] = v;
+}
+
+// out[b, c] = sum over the N rows of x[b, :, c] -- the gradient of a broadcast row vector.  One workgroup per (sample,
+// 64 columns): four row phases of 64 lanes each read coalesced 256-byte rows, partial sums meet in LDS in a fixed
+// order (no atomics: the result does not depend on scheduling).
+__global__ __launch_bounds__(256) void rows_sum_kernel(float *__restrict__ out, const float *__restrict__ x, int N, int C) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const long b = blockIdx.y;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < C) {
+    const float *xb = x + b * (long)N * C + c;
+    int r = ph;
+    for (; r + 12 < N; r += 16) {
+      s0 += xb[(long)r * C];
+      s1 += xb[(long)(r + 4) * C];
+      s2 += xb[(long)(r + 8) * C];
+      s3 += xb[(long)(r + 12) * C];
+    }
+    for (; r < N; r += 4) s0 += xb[(long)r * C];
+  }
+  part[ph][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ph == 0 && c < C) out[b * C + c] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
 }  // namespace hipad
 
 using namespace hipad;
@@ -261,6 +309,23 @@ int hipad_step_offsets(float *out, const float *x, long long rows, int steps, in
   if (n >= (1l << 40)) return HIPAD_ERANGE;
   hipLaunchKernelGGL(step_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, x, n,
                      steps, dims, adjoint ? 1 : 0);
+  return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
+}
+
+int hipad_add_rows(float *out, const float *base, const float *rows0, const float *rows1, const float *rows2, int bs,
+                   int n_rows, int channels, hipad_stream_t stream) {
+  if (!out || !base || !rows0 || bs <= 0 || n_rows <= 0 || channels <= 0 || (channels & 3)) return HIPAD_EINVAL;
+  if ((((uintptr_t)out | (uintptr_t)base | (uintptr_t)rows0 | (uintptr_t)rows1 | (uintptr_t)rows2) & 15) != 0) return HIPAD_EINVAL;
+  const long n4 = (long)bs * n_rows * (channels / 4);
+  hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, base, rows0,
+                     rows1, rows2, n4, n_rows, channels / 4);
+  return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
+}
+
+int hipad_rows_sum(float *out, const float *x, int bs, int n_rows, int channels, hipad_stream_t stream) {
+  if (!out || !x || bs <= 0 || n_rows <= 0 || channels <= 0) return HIPAD_EINVAL;
+  hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)((channels + 63) / 64), (unsigned)bs), dim3(256), 0, (hipStream_t)stream,
+                     out, x, n_rows, channels);
   return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
 }
 

@@ -117,12 +117,22 @@ __device__ __forceinline__ void online_merge(float &m, float &s, float m2, float
   m = mn;
 }
 
+// Index arithmetic: the layouts below are walked with flat indices that have to be split by RUNTIME divisors (cams * L * G,
+// L * G, P, n).  A 32-bit integer division is ~35 VALU instructions on gfx950; with three of them per weight the kernels
+// were bound by exactly that (map head: 57 600 weights per workgroup, 62 us forward).  For indices below 2^22 the quotient
+// is exact from one float multiply: |(x + 0.5) * fl(1/d) - (x + 0.5)/d| <= (x/d) 2^-23 < 0.5/d.  FAST = false keeps the
+// integer division for larger problems.
+template <bool FAST>
+__device__ __forceinline__ int idiv(int x, int d, float inv) {
+  return FAST ? (int)(((float)x + 0.5f) * inv) : x / d;
+}
+
 // Work decomposition (both directions): one workgroup per (b, anchor); T = 256 threads, or 1024 when the
 // anchor has >= 4096 logits (the map head: 100 anchors x 57 600 weights would otherwise sit on 100 x 4 waves).
 // T is a multiple of G, so a thread meets one group g = tid % G in both index orders used below:
 //   j-order  j = (l*P + p)*G + g            the layout of u / v / grad_u   (coalesced reads of u, v)
 //   o-order  o = ((p*cams + cam)*L + l)*G + g   the op layout of weights   (coalesced writes / reads of w)
-template <int T>
+template <int T, bool FAST>
 __global__ __launch_bounds__(T) void weights_softmax_fwd_kernel(
     float *__restrict__ w, float *__restrict__ stats, const float *__restrict__ u,
     const float *__restrict__ v, const float *__restrict__ keep, int A, int cams, int L, int P, int G,
@@ -134,6 +144,9 @@ __global__ __launch_bounds__(T) void weights_softmax_fwd_kernel(
   const int n = L * P * G;
   const float *ua = u + ba * (ucs ? (long)cams * n : (long)n);
   const float *vb = v ? v + b * cams * n : nullptr;
+  const int LG = L * G, CLG = cams * LG;
+  const int gshift = __builtin_ctz(G);  // G divides 256: a power of two
+  const float inv_n = 1.f / (float)n, inv_clg = 1.f / (float)CLG, inv_lg = 1.f / (float)LG;
   // pass 1 (j-order, cameras flattened: entry e = cam*n + j keeps e % G == tid % G because G | n): online max / sum
   // over this thread's entries, four loads in flight per trip (one load per trip left the kernel waiting a memory
   // latency per element: 31 us for 9 MB of weights)
@@ -146,7 +159,7 @@ __global__ __launch_bounds__(T) void weights_softmax_fwd_kernel(
       const int e = e0 + q * T;
       xs[q] = -INFINITY;
       if (e < total) {
-        const int cam = e / n, j = e - cam * n;
+        const int cam = idiv<FAST>(e, n, inv_n), j = e - cam * n;
         xs[q] = ua[(long)cam * ucs + j] + (vb ? vb[e] : 0.f);
       }
     }
@@ -168,24 +181,28 @@ __global__ __launch_bounds__(T) void weights_softmax_fwd_kernel(
   }
   const int g = tid % G;
   const float gm = red_m[g], gs = red_s[g];
-  if (tid < G) {
+  // gridDim.y workgroups share one anchor when there are too few anchors to fill the chip (the map head: 100): each
+  // repeats the reduction above (u / v come from L2) and writes its own slice of the weights.  Slices start at
+  // multiples of T, so a thread keeps its group.
+  const int slice = ((total + (int)gridDim.y - 1) / (int)gridDim.y + T - 1) / T * T;
+  const int o_lo = blockIdx.y * slice, o_hi = min(total, o_lo + slice);
+  if (tid < G && blockIdx.y == 0) {
     stats[(ba * G + tid) * 2 + 0] = gm;
     stats[(ba * G + tid) * 2 + 1] = gs;
   }
   const float inv = 1.f / gs;
   // pass 2 (o-order): consecutive threads write consecutive weights; u / v are gathered (32-byte runs, L1/L2)
   float *wa = w + ba * (long)cams * n;
-  const int LG = L * G, CLG = cams * LG;
-  for (int o0 = tid; o0 < total; o0 += 4 * T) {
+  for (int o0 = o_lo + tid; o0 < o_hi; o0 += 4 * T) {
     float lg4[4], kp4[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int o = min(o0 + q * T, total - 1);  // past the end: a repeat of the last element, not stored
-      const int p = o / CLG;
+      const int o = min(o0 + q * T, o_hi - 1);  // past the end: a repeat of the last element, not stored
+      const int p = idiv<FAST>(o, CLG, inv_clg);
       const int r = o - p * CLG;
-      const int cam = r / LG;
+      const int cam = idiv<FAST>(r, LG, inv_lg);
       const int lg = r - cam * LG;           // l*G + g
-      const int l = lg / G;
+      const int l = lg >> gshift;
       const int j = (l * P + p) * G + g;
       lg4[q] = ua[(long)cam * ucs + j] + (vb ? vb[(long)cam * n + j] : 0.f);
       kp4[q] = keep ? keep[(ba * cams + cam) * P + p] : 1.f;
@@ -193,7 +210,7 @@ __global__ __launch_bounds__(T) void weights_softmax_fwd_kernel(
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int o = o0 + q * T;
-      if (o < total) wa[o] = __expf(lg4[q] - gm) * inv * kp4[q];
+      if (o < o_hi) wa[o] = __expf(lg4[q] - gm) * inv * kp4[q];
     }
   }
 }
@@ -201,7 +218,7 @@ __global__ __launch_bounds__(T) void weights_softmax_fwd_kernel(
 // backward: grad_x[a, cam, j] = softmax * (grad_w * keep - dot[a, g]);  grad_u = grad_x (per camera) or its sum over
 // the cameras; the camera part grad_v[b, cam, j] = sum over anchors is NOT accumulated here with A-way contended
 // atomics: grad_x is written to `gx_tmp` [bs*A, cams, n] (coalesced) and summed over the anchors by colsum_kernel.
-template <int T>
+template <int T, bool FAST>
 __global__ __launch_bounds__(T) void weights_softmax_bwd_kernel(
     float *__restrict__ gu, float *__restrict__ gx_tmp, const float *__restrict__ gw,
     const float *__restrict__ stats, const float *__restrict__ u, const float *__restrict__ v,
@@ -218,6 +235,8 @@ __global__ __launch_bounds__(T) void weights_softmax_bwd_kernel(
   const float gm = stats[(ba * G + g) * 2 + 0];
   const float inv = 1.f / stats[(ba * G + g) * 2 + 1];
   const int LG = L * G, CLG = cams * LG;
+  const int gshift = __builtin_ctz(G);
+  const float inv_clg = 1.f / (float)CLG, inv_lg = 1.f / (float)LG, inv_p = 1.f / (float)P;
   // dot[g] = sum over the softmax set of (d w) * softmax   (o-order: coalesced reads of grad_w)
   float dot = 0.f;
   const int total = cams * n;
@@ -229,11 +248,11 @@ __global__ __launch_bounds__(T) void weights_softmax_bwd_kernel(
       gy4[q] = 0.f;
       lg4[q] = gm;
       if (o < total) {
-        const int p = o / CLG;
+        const int p = idiv<FAST>(o, CLG, inv_clg);
         const int r = o - p * CLG;
-        const int cam = r / LG;
+        const int cam = idiv<FAST>(r, LG, inv_lg);
         const int lg = r - cam * LG;
-        const int l = lg / G;
+        const int l = lg >> gshift;
         const int j = (l * P + p) * G + g;
         gy4[q] = gwa[o] * (keep ? keep[(ba * cams + cam) * P + p] : 1.f);
         lg4[q] = ua[(long)cam * ucs + j] + (vb ? vb[(long)cam * n + j] : 0.f);
@@ -252,9 +271,12 @@ __global__ __launch_bounds__(T) void weights_softmax_bwd_kernel(
   // j-order: coalesced writes of grad_u / gx_tmp; grad_w gathered in 32-byte runs
   float *gua = gu + ba * (ucs ? (long)cams * n : (long)n);
   float *gxa = gx_tmp ? gx_tmp + ba * (long)cams * n : nullptr;
-  for (int j = tid; j < n; j += T) {
-    const int lp = j / G;
-    const int l = lp / P, p = lp - l * P;
+  // (gridDim.y workgroups per anchor: every one computes the dot products above, each writes its slice of j)
+  const int slice = ((n + (int)gridDim.y - 1) / (int)gridDim.y + T - 1) / T * T;
+  const int j_lo = blockIdx.y * slice, j_hi = min(n, j_lo + slice);
+  for (int j = j_lo + tid; j < j_hi; j += T) {
+    const int lp = j >> gshift;
+    const int l = idiv<FAST>(lp, P, inv_p), p = lp - l * P;
     float acc = 0.f;
     for (int cam0 = 0; cam0 < cams; cam0 += 3) {
       float gy3[3], lg3[3];
@@ -276,6 +298,206 @@ __global__ __launch_bounds__(T) void weights_softmax_bwd_kernel(
     }
     if (!ucs) gua[j] = acc;
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// (2b) The same two kernels with FOUR groups per thread (G % 4 == 0, 16-byte aligned tensors): every load and store is a
+// float4.  The scalar kernels above keep four 4-byte loads per thread in flight; with a dependent memory round trip
+// costing ~2 us that bounds a workgroup of 1024 threads at ~16 KB per round trip (map head, 57 600 logits per anchor: 14
+// round trips for the reduction alone, 41 us forward / 64 us backward measured).  Index names with a 4 count float4s:
+// Q = G / 4 quads per (l, p), a thread meets the quad tid % Q everywhere (Q | T, slices are multiples of T).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 ld4(const float *p, long i4) { return reinterpret_cast<const float4 *>(p)[i4]; }
+__device__ __forceinline__ float4 add4(const float4 &a, const float4 &b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
+template <int T, bool FAST>
+__global__ __launch_bounds__(T) void weights_softmax_fwd4_kernel(
+    float *__restrict__ w, float *__restrict__ stats, const float *__restrict__ u, const float *__restrict__ v,
+    const float *__restrict__ keep, int A, int cams, int L, int P, int G, int ucs) {
+  __shared__ float4 red_m[T], red_s[T];
+  const int tid = threadIdx.x;
+  const long ba = blockIdx.x;
+  const long b = ba / A;
+  const int n = L * P * G, n4 = n >> 2, Q = G >> 2, ucs4 = ucs >> 2;
+  const int qshift = __builtin_ctz(Q);
+  const int total4 = cams * n4, LQ = L * Q, CLQ = cams * LQ;
+  const float inv_n4 = 1.f / (float)n4, inv_clq = 1.f / (float)CLQ, inv_lq = 1.f / (float)LQ;
+  const float *ua = u + ba * (ucs ? (long)cams * n : (long)n);
+  const float *vb = v ? v + b * cams * n : nullptr;
+  float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, sm[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int e0 = tid; e0 < total4; e0 += 4 * T) {
+    float xs[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = e0 + q * T;
+      float4 x = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      if (e < total4) {
+        const int cam = idiv<FAST>(e, n4, inv_n4), j4 = e - cam * n4;
+        x = ld4(ua, (long)cam * ucs4 + j4);
+        if (vb) x = add4(x, ld4(vb, e));
+      }
+      xs[q][0] = x.x; xs[q][1] = x.y; xs[q][2] = x.z; xs[q][3] = x.w;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float mn = fmaxf(fmaxf(m[c], xs[0][c]), fmaxf(fmaxf(xs[1][c], xs[2][c]), xs[3][c]));  // xs[0] is a real entry
+      sm[c] = sm[c] * __expf(m[c] - mn) +
+              ((__expf(xs[0][c] - mn) + __expf(xs[1][c] - mn)) + (__expf(xs[2][c] - mn) + __expf(xs[3][c] - mn)));
+      m[c] = mn;
+    }
+  }
+  red_m[tid] = make_float4(m[0], m[1], m[2], m[3]);
+  red_s[tid] = make_float4(sm[0], sm[1], sm[2], sm[3]);
+  __syncthreads();
+  for (int stride = T / 2; stride >= Q; stride >>= 1) {
+    if (tid < stride) {
+      float4 am = red_m[tid], as = red_s[tid];
+      const float4 bm = red_m[tid + stride], bsum = red_s[tid + stride];
+      online_merge(am.x, as.x, bm.x, bsum.x);
+      online_merge(am.y, as.y, bm.y, bsum.y);
+      online_merge(am.z, as.z, bm.z, bsum.z);
+      online_merge(am.w, as.w, bm.w, bsum.w);
+      red_m[tid] = am;
+      red_s[tid] = as;
+    }
+    __syncthreads();
+  }
+  const int quad = tid & (Q - 1);
+  const float4 gm = red_m[quad], gs = red_s[quad];
+  if (tid < Q && blockIdx.y == 0) {
+    float *st = stats + (ba * G + tid * 4) * 2;
+    st[0] = gm.x; st[1] = gs.x; st[2] = gm.y; st[3] = gs.y; st[4] = gm.z; st[5] = gs.z; st[6] = gm.w; st[7] = gs.w;
+  }
+  const float4 inv = make_float4(1.f / gs.x, 1.f / gs.y, 1.f / gs.z, 1.f / gs.w);
+  const int slice = ((total4 + (int)gridDim.y - 1) / (int)gridDim.y + T - 1) / T * T;
+  const int o_lo = blockIdx.y * slice, o_hi = min(total4, o_lo + slice);
+  float4 *wa = reinterpret_cast<float4 *>(w + ba * (long)cams * n);
+  for (int o0 = o_lo + tid; o0 < o_hi; o0 += 4 * T) {
+    float4 lg4[4];
+    float kp4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int o = min(o0 + q * T, o_hi - 1);  // past the end: a repeat of the last element, not stored
+      const int p = idiv<FAST>(o, CLQ, inv_clq);
+      const int r = o - p * CLQ;
+      const int cam = idiv<FAST>(r, LQ, inv_lq);
+      const int l = (r - cam * LQ) >> qshift;
+      const int j4 = (l * P + p) * Q + quad;
+      lg4[q] = ld4(ua, (long)cam * ucs4 + j4);
+      if (vb) lg4[q] = add4(lg4[q], ld4(vb, (long)cam * n4 + j4));
+      kp4[q] = keep ? keep[(ba * cams + cam) * P + p] : 1.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int o = o0 + q * T;
+      if (o < o_hi)
+        wa[o] = make_float4(__expf(lg4[q].x - gm.x) * inv.x * kp4[q], __expf(lg4[q].y - gm.y) * inv.y * kp4[q],
+                            __expf(lg4[q].z - gm.z) * inv.z * kp4[q], __expf(lg4[q].w - gm.w) * inv.w * kp4[q]);
+    }
+  }
+}
+
+template <int T, bool FAST>
+__global__ __launch_bounds__(T) void weights_softmax_bwd4_kernel(
+    float *__restrict__ gu, float *__restrict__ gx_tmp, const float *__restrict__ gw, const float *__restrict__ stats,
+    const float *__restrict__ u, const float *__restrict__ v, const float *__restrict__ keep, int A, int cams, int L,
+    int P, int G, int ucs) {
+  __shared__ float4 red[T];
+  const int tid = threadIdx.x;
+  const long ba = blockIdx.x;
+  const long b = ba / A;
+  const int n = L * P * G, n4 = n >> 2, Q = G >> 2, ucs4 = ucs >> 2;
+  const int qshift = __builtin_ctz(Q);
+  const int total4 = cams * n4, LQ = L * Q, CLQ = cams * LQ;
+  const float inv_clq = 1.f / (float)CLQ, inv_lq = 1.f / (float)LQ, inv_p = 1.f / (float)P;
+  const float *ua = u + ba * (ucs ? (long)cams * n : (long)n);
+  const float *vb = v ? v + b * cams * n : nullptr;
+  const float *gwa = gw + ba * (long)cams * n;
+  const int quad = tid & (Q - 1);
+  const float *st = stats + (ba * G + quad * 4) * 2;
+  const float4 gm = make_float4(st[0], st[2], st[4], st[6]);
+  const float4 inv = make_float4(1.f / st[1], 1.f / st[3], 1.f / st[5], 1.f / st[7]);
+  float4 dot = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int o0 = tid; o0 < total4; o0 += 4 * T) {
+    float4 gy4[4], lg4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int o = o0 + q * T;
+      gy4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      lg4[q] = gm;
+      if (o < total4) {
+        const int p = idiv<FAST>(o, CLQ, inv_clq);
+        const int r = o - p * CLQ;
+        const int cam = idiv<FAST>(r, LQ, inv_lq);
+        const int l = (r - cam * LQ) >> qshift;
+        const int j4 = (l * P + p) * Q + quad;
+        const float kp = keep ? keep[(ba * cams + cam) * P + p] : 1.f;
+        const float4 gyr = ld4(gwa, o);
+        gy4[q] = make_float4(gyr.x * kp, gyr.y * kp, gyr.z * kp, gyr.w * kp);
+        lg4[q] = ld4(ua, (long)cam * ucs4 + j4);
+        if (vb) lg4[q] = add4(lg4[q], ld4(vb, (long)cam * n4 + j4));
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      dot.x += gy4[q].x * __expf(lg4[q].x - gm.x) * inv.x;
+      dot.y += gy4[q].y * __expf(lg4[q].y - gm.y) * inv.y;
+      dot.z += gy4[q].z * __expf(lg4[q].z - gm.z) * inv.z;
+      dot.w += gy4[q].w * __expf(lg4[q].w - gm.w) * inv.w;
+    }
+  }
+  red[tid] = dot;
+  __syncthreads();
+  for (int stride = T / 2; stride >= Q; stride >>= 1) {
+    if (tid < stride) red[tid] = add4(red[tid], red[tid + stride]);
+    __syncthreads();
+  }
+  const float4 gdot = red[quad];
+  float *gua = gu + ba * (ucs ? (long)cams * n : (long)n);
+  float *gxa = gx_tmp ? gx_tmp + ba * (long)cams * n : nullptr;
+  const int slice = ((n4 + (int)gridDim.y - 1) / (int)gridDim.y + T - 1) / T * T;
+  const int j_lo = blockIdx.y * slice, j_hi = min(n4, j_lo + slice);
+  for (int j4 = j_lo + tid; j4 < j_hi; j4 += T) {
+    const int lp = j4 >> qshift;
+    const int l = idiv<FAST>(lp, P, inv_p), p = lp - l * P;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int cam0 = 0; cam0 < cams; cam0 += 3) {
+      float4 gy3[3], lg3[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int cam = min(cam0 + q, cams - 1);
+        const float kp = keep ? keep[(ba * cams + cam) * P + p] : 1.f;
+        const float4 gyr = ld4(gwa, (((long)p * cams + cam) * L + l) * Q + quad);
+        gy3[q] = make_float4(gyr.x * kp, gyr.y * kp, gyr.z * kp, gyr.w * kp);
+        lg3[q] = ld4(ua, (long)cam * ucs4 + j4);
+        if (vb) lg3[q] = add4(lg3[q], ld4(vb, (long)cam * n4 + j4));
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int cam = cam0 + q;
+        if (cam < cams) {
+          const float4 gx = make_float4(__expf(lg3[q].x - gm.x) * inv.x * (gy3[q].x - gdot.x),
+                                        __expf(lg3[q].y - gm.y) * inv.y * (gy3[q].y - gdot.y),
+                                        __expf(lg3[q].z - gm.z) * inv.z * (gy3[q].z - gdot.z),
+                                        __expf(lg3[q].w - gm.w) * inv.w * (gy3[q].w - gdot.w));
+          if (ucs) reinterpret_cast<float4 *>(gua)[(long)cam * ucs4 + j4] = gx; else acc = add4(acc, gx);
+          if (gxa) reinterpret_cast<float4 *>(gxa)[(long)cam * n4 + j4] = gx;
+        }
+      }
+    }
+    if (!ucs) reinterpret_cast<float4 *>(gua)[j4] = acc;
+  }
+}
+
+// workgroups per anchor of the weights-softmax kernels (hipad_weights_softmax_set_split overrides; 0 = automatic)
+static int g_wsm_split = 0;
+static int wsm_split(int anchors, bool big) {
+  if (g_wsm_split > 0) return g_wsm_split;
+  if (!big) return 1;
+  int k = 384 / (anchors > 0 ? anchors : 1);
+  return k < 1 ? 1 : (k > 2 ? 2 : k);
 }
 
 // out[b, c] = sum over a of x[b, a, c]: each workgroup sums a slab of `rows_per_block` anchors for 256 columns
@@ -328,18 +550,34 @@ int hipad_project_points_backward(float *grad_key_points, const float *grad_loc,
   return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
 }
 
+void hipad_weights_softmax_set_split(int workgroups_per_anchor) {
+  g_wsm_split = workgroups_per_anchor > 0 && workgroups_per_anchor <= 16 ? workgroups_per_anchor : 0;
+}
+
 int hipad_weights_softmax_forward(float *weights, float *stats, const float *u, const float *v,
                                   const float *keep, int bs, int A, int cams, int L, int P, int G,
                                   int u_per_cam, hipad_stream_t stream) {
   if (!weights || !stats || !u) return HIPAD_EINVAL;
   if (bs <= 0 || A <= 0 || cams <= 0 || L <= 0 || P <= 0 || G <= 0 || 256 % G) return HIPAD_EINVAL;
   const int n = L * P * G;
-  if (n >= 4096 && 1024 % G == 0)
-    hipLaunchKernelGGL(weights_softmax_fwd_kernel<1024>, dim3((unsigned)(bs * A)), dim3(1024), 0, (hipStream_t)stream,
-                       weights, stats, u, v, keep, A, cams, L, P, G, u_per_cam ? n : 0);
-  else
-    hipLaunchKernelGGL(weights_softmax_fwd_kernel<256>, dim3((unsigned)(bs * A)), dim3(256), 0, (hipStream_t)stream,
-                       weights, stats, u, v, keep, A, cams, L, P, G, u_per_cam ? n : 0);
+  const bool fast = (long)cams * n < (1l << 22);
+  const bool big = (long)cams * n >= 8192 && 1024 % G == 0;   // 1024 threads per anchor from 8192 logits on
+  const int split = wsm_split(bs * A, big);
+  const bool vec4 = (G & 3) == 0 && (((uintptr_t)weights | (uintptr_t)u | (uintptr_t)v) & 15) == 0;
+#define HIPAD_WSM_FWD(K, T, F)                                                                                         \
+  hipLaunchKernelGGL((K<T, F>), dim3((unsigned)(bs * A), split), dim3(T), 0, (hipStream_t)stream, weights, stats, u, v, \
+                     keep, A, cams, L, P, G, u_per_cam ? n : 0)
+#define HIPAD_WSM_FWD_T(K)                                                        \
+  do {                                                                            \
+    if (big) {                                                                    \
+      if (fast) HIPAD_WSM_FWD(K, 1024, true); else HIPAD_WSM_FWD(K, 1024, false); \
+    } else {                                                                      \
+      if (fast) HIPAD_WSM_FWD(K, 256, true); else HIPAD_WSM_FWD(K, 256, false);   \
+    }                                                                             \
+  } while (0)
+  if (vec4) HIPAD_WSM_FWD_T(weights_softmax_fwd4_kernel); else HIPAD_WSM_FWD_T(weights_softmax_fwd_kernel);
+#undef HIPAD_WSM_FWD_T
+#undef HIPAD_WSM_FWD
   return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
 }
 
@@ -362,12 +600,25 @@ int hipad_weights_softmax_backward(float *grad_u, float *grad_v, const float *gr
     gx_tmp = (float *)workspace;
     if (fill_zero(grad_v, (size_t)bs * cams * n * sizeof(float), stream) != HIPAD_OK) return HIPAD_ELAUNCH;
   }
-  if (n >= 4096 && 1024 % G == 0)
-    hipLaunchKernelGGL(weights_softmax_bwd_kernel<1024>, dim3((unsigned)(bs * A)), dim3(1024), 0, stream, grad_u, gx_tmp,
-                       grad_weights, stats, u, v, keep, A, cams, L, P, G, u_per_cam ? n : 0);
-  else
-    hipLaunchKernelGGL(weights_softmax_bwd_kernel<256>, dim3((unsigned)(bs * A)), dim3(256), 0, stream, grad_u, gx_tmp,
-                       grad_weights, stats, u, v, keep, A, cams, L, P, G, u_per_cam ? n : 0);
+  const bool fast = (long)cams * n < (1l << 22);
+  const bool big = (long)cams * n >= 8192 && 1024 % G == 0;
+  const int split = wsm_split(bs * A, big);
+  const bool vec4 = (G & 3) == 0 &&
+                    (((uintptr_t)grad_u | (uintptr_t)gx_tmp | (uintptr_t)grad_weights | (uintptr_t)u | (uintptr_t)v) & 15) == 0;
+#define HIPAD_WSM_BWD(K, T, F)                                                                                      \
+  hipLaunchKernelGGL((K<T, F>), dim3((unsigned)(bs * A), split), dim3(T), 0, stream, grad_u, gx_tmp, grad_weights,   \
+                     stats, u, v, keep, A, cams, L, P, G, u_per_cam ? n : 0)
+#define HIPAD_WSM_BWD_T(K)                                                        \
+  do {                                                                            \
+    if (big) {                                                                    \
+      if (fast) HIPAD_WSM_BWD(K, 1024, true); else HIPAD_WSM_BWD(K, 1024, false); \
+    } else {                                                                      \
+      if (fast) HIPAD_WSM_BWD(K, 256, true); else HIPAD_WSM_BWD(K, 256, false);   \
+    }                                                                             \
+  } while (0)
+  if (vec4) HIPAD_WSM_BWD_T(weights_softmax_bwd4_kernel); else HIPAD_WSM_BWD_T(weights_softmax_bwd_kernel);
+#undef HIPAD_WSM_BWD_T
+#undef HIPAD_WSM_BWD
   if (v) {
     const long cols = (long)cams * n;
     // enough workgroups to cover the chip: slabs of anchors when there are few columns

@@ -573,6 +573,37 @@ def focal_loss(logits, target, weight=None, avg_factor=None, layers=1, alpha=0.2
     return _FocalLoss.apply(logits, target, weight, avg_factor, int(layers), float(alpha), float(gamma))
 
 
+class _AddRows(Function):
+    @staticmethod
+    def forward(ctx, base, *rows):
+        ctx.shapes = [tuple(r.shape) for r in rows]
+        return _lib.add_rows(_c32(base), [_c32(r) for r in rows])
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        g = _c32(gout)
+        gr = None
+        if any(ctx.needs_input_grad[1:]):
+            gr = _lib.rows_sum(g)                       # one reduction serves every row vector
+        return (g,) + tuple(gr.view(s) if need else None for s, need in zip(ctx.shapes, ctx.needs_input_grad[1:]))
+
+
+def add_rows(base, *rows):
+    """``base`` (bs, N, C) plus row vectors (bs, 1, C) / (bs, C) broadcast over the N rows: one launch forward; backward
+    hands the output gradient to ``base`` as is and ONE row sum to all the vectors (include/hipad.h: hipad_add_rows)."""
+    rows = [r for r in rows if r is not None]
+    if not rows:
+        return base
+    if (not base.is_cuda or base.dim() != 3 or base.shape[-1] % 4 or len(rows) > 3
+            or any(r.numel() != base.shape[0] * base.shape[-1] for r in rows)):
+        out = base
+        for r in rows:
+            out = out + r
+        return out
+    return _AddRows.apply(base, *rows)
+
+
 class _StepOffsets(Function):
     @staticmethod
     def forward(ctx, x):

@@ -27,6 +27,7 @@ SIGNATURES = {
     "hipad_daf_taps": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
     "hipad_daf_set_tap_chunks": (None, [c_int]),
     "hipad_daf_set_feat_run": (None, [c_int]),
+    "hipad_weights_softmax_set_split": (None, [c_int]),
     "hipad_daf_backward_feat_multi_workspace": (c_size_t, [c_void_p, c_int] + [c_int] * 6),
     "hipad_daf_backward_feat_multi": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 6
                                       + [c_void_p, c_size_t, c_void_p]),
@@ -74,6 +75,8 @@ SIGNATURES = {
                                                                       c_void_p]),
     "hipad_motion_query_embed": (c_int, [c_void_p] * 5 + [ctypes.c_longlong] + [c_int] * 7 + [c_void_p]),
     "hipad_accumulate_bf16": (c_int, [c_void_p, c_int, c_void_p]),
+    "hipad_add_rows": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),
+    "hipad_rows_sum": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p]),
     "hipad_step_offsets": (c_int, [c_void_p] * 2 + [ctypes.c_longlong] + [c_int] * 3 + [c_void_p]),
     "hipad_chain_forward": (c_int, [c_void_p, c_int, c_void_p]),
     "hipad_chain_debug_stamps": (None, [c_void_p]),
@@ -753,6 +756,38 @@ def accumulate_bf16(pairs):
             chunk = items[i:i + ACC_MAX]
             arr = (AccItem * len(chunk))(*chunk)
             check(lib.hipad_accumulate_bf16(arr, len(chunk), stream_ptr(dev)), "hipad_accumulate_bf16")
+
+
+def add_rows(base, rows):
+    """base (bs, N, C) + every (bs, C) tensor of ``rows`` (1..3) broadcast over the N rows, one launch."""
+    lib = load()
+    _req(base, torch.float32, "base")
+    if base.dim() != 3 or not 1 <= len(rows) <= 3:
+        raise HipadError("add_rows: base must be (bs, N, C) and 1..3 row tensors given")
+    bs, N, C = base.shape
+    for k, r in enumerate(rows):
+        _req(r, torch.float32, f"rows[{k}]")
+        if r.numel() != bs * C:
+            raise HipadError(f"add_rows: rows[{k}] has {r.numel()} elements, expected {bs} x {C}")
+    out = torch.empty_like(base)
+    ptrs = [r.data_ptr() for r in rows] + [None] * (3 - len(rows))
+    with torch.cuda.device(base.device):
+        check(lib.hipad_add_rows(out.data_ptr(), base.data_ptr(), ptrs[0], ptrs[1], ptrs[2], bs, N, C,
+                                 stream_ptr(base.device)), "hipad_add_rows")
+    return out
+
+
+def rows_sum(x):
+    """(bs, N, C) -> (bs, C): sum over the rows of every sample, fixed order."""
+    lib = load()
+    _req(x, torch.float32, "x")
+    if x.dim() != 3 or x.numel() == 0:
+        raise HipadError("rows_sum: x must be (bs, N, C), non-empty")
+    bs, N, C = x.shape
+    out = torch.empty(bs, C, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.hipad_rows_sum(out.data_ptr(), x.data_ptr(), bs, N, C, stream_ptr(x.device)), "hipad_rows_sum")
+    return out
 
 
 def step_offsets(x, adjoint=False):

@@ -211,6 +211,9 @@ int hipad_weights_softmax_forward(float *weights, float *stats, const float *u, 
                                   hipad_stream_t stream);
 /* backward scratch (bytes): the per-(anchor, camera) logit gradients before they are summed over the anchors
  * into grad_v; 0 when there is no camera part (has_v == 0) */
+/* Tuning knob: workgroups per (sample, anchor) of the two kernels (each repeats the reduction, writes its slice);
+ * 1..16, anything else = automatic (2 when fewer than ~200 anchors of >= 8192 logits exist, else 1). */
+void hipad_weights_softmax_set_split(int workgroups_per_anchor);
 size_t hipad_weights_softmax_backward_workspace(int batch_size, int num_anchors, int num_cams, int num_scale,
                                                 int num_pts, int num_groups, int has_v);
 int hipad_weights_softmax_backward(float *grad_u, float *grad_v, const float *grad_weights,
@@ -618,6 +621,12 @@ int hipad_pack_weights(unsigned short *const *dst, unsigned short *const *dst_t,
  *   concatenate launches forward, their slice-backward fills and joins backward).  x, out: (rows, steps, dims) fp32,
  *   out != x; out[t] = x[t] - x[t-1], out[0] = x[0]; adjoint != 0 applies the transposed map (a gradient's backward):
  *   out[t] = x[t] - x[t+1], out[steps-1] = x[steps-1].
+ * hipad_add_rows / hipad_rows_sum.  Replaces: the planning branch's broadcast additions `embed + target-point embed +
+ *   command embed + ego embed` and `feature + ego feature` (reference models/sparse_onedecoder.py, plan refinement: one
+ *   launch per addend forward, one two-workgroup column reduction per addend backward).  base, out: (bs, n_rows,
+ *   channels); rows0..2 (rows1 / rows2 may be NULL): (bs, channels), added to every row of their sample; channels % 4
+ *   == 0, 16-byte aligned.  hipad_rows_sum: out (bs, channels) = sum over the rows of x (bs, n_rows, channels) -- the
+ *   gradient of each row vector (the same for all of them); fixed summation order, no atomics.
  * hipad_keep_mask.  Replaces: the Bernoulli keep mask of DeformableFeatureAggregation's attn_drop (reference
  *   models/blocks.py:209-212; rand, compare, cast, rescale = four launches): out[i] = 1 / (1 - p_drop) with probability
  *   1 - p_drop else 0, drawn from (seed, *seed_dev, i) -- seed_dev (may be NULL) is a device step counter, so a replayed
@@ -642,6 +651,9 @@ int hipad_chunk_mix(float *out, const float *x0, const float *x1, const float *w
 int hipad_motion_query_embed(float *out, const float *cls, const float *box, const float *table, const float *freq,
                              long long n_anchor, int num_classes, int box_dim, int sin_col, int cos_col, int modes,
                              int steps, int half_dim, hipad_stream_t stream);
+int hipad_add_rows(float *out, const float *base, const float *rows0, const float *rows1, const float *rows2, int bs,
+                   int n_rows, int channels, hipad_stream_t stream);
+int hipad_rows_sum(float *out, const float *x, int bs, int n_rows, int channels, hipad_stream_t stream);
 int hipad_step_offsets(float *out, const float *x, long long rows, int steps, int dims, int adjoint, hipad_stream_t stream);
 
 /* ------------------------------------------------------------------------------------

@@ -533,14 +533,13 @@ class SparseOneDecoder(DecoderLoss, BaseModule):
                     outs["ego"]["status"].append(self.ego_refine[refine_i](g.feature, g.embed))
                 if "plan" in self.task_select:
                     p = br["plan"]
-                    embed = p.embed
-                    if self.with_target_point_embed:
-                        embed = embed + self._tp_embed
-                    if self.with_command_embed:
-                        embed = embed + self._cmd_embed
-                    if self.with_ego_instance_feature:
-                        p.feature = p.feature + br["ego"].feature
-                        embed = embed + br["ego"].embed
+                    # the row vectors (bs, 1, C) are broadcast over the plan queries: one launch per sum
+                    ego_b = br["ego"] if self.with_ego_instance_feature else None
+                    embed = HF.add_rows(p.embed, self._tp_embed if self.with_target_point_embed else None,
+                                        self._cmd_embed if self.with_command_embed else None,
+                                        ego_b.embed if ego_b is not None else None)
+                    if ego_b is not None:
+                        p.feature = HF.add_rows(p.feature, ego_b.feature)
                     plan_reg, plan_cls = self.plan_refine[refine_i](p.feature, p.anchor, embed, True)
                     p.anchor = plan_reg
                     bs, nj, _ = plan_reg.shape

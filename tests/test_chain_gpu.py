@@ -292,6 +292,34 @@ def test_step_offsets_match_the_slice_and_concatenate_expression():
         lib.step_offsets(torch.zeros(2, 3, 2, device="cuda", dtype=torch.float64))
 
 
+def test_add_rows_matches_broadcast_additions():
+    """base + row vectors broadcast over a sample's rows: forward equal to the chained torch additions (same order of
+    fp32 additions: bit-equal), one shared row-sum gradient for the vectors."""
+    from hipad_amd import functional as HF
+    g = torch.Generator().manual_seed(10)
+    for bs, N, C, k in [(2, 480, 256, 3), (1, 7, 64, 1), (3, 901, 256, 2)]:
+        base = torch.randn(bs, N, C, generator=g).cuda().requires_grad_(True)
+        rows = [torch.randn(bs, 1, C, generator=g).cuda().requires_grad_(True) for _ in range(k)]
+        out = HF.add_rows(base, *rows)
+        go = torch.randn(out.shape, generator=g).cuda()
+        out.backward(go)
+        b2 = base.detach().clone().requires_grad_(True)
+        r2 = [r.detach().clone().requires_grad_(True) for r in rows]
+        ref = b2
+        for r in r2:
+            ref = ref + r
+        ref.backward(go)
+        assert torch.equal(out, ref) and torch.equal(base.grad, b2.grad)
+        for a, b in zip(rows, r2):
+            assert a.grad.shape == b.grad.shape
+            assert float((a.grad - b.grad).abs().max()) <= 1e-5 * float(b.grad.abs().max())
+    # None entries are skipped; shapes the kernel does not take fall back to torch additions
+    x = torch.randn(2, 5, 6, generator=g).cuda()
+    assert torch.equal(HF.add_rows(x, None, None), x)
+    r = torch.randn(2, 1, 6, generator=g).cuda()
+    assert torch.equal(HF.add_rows(x, r), x + r)
+
+
 def test_keep_mask_statistics_and_clock():
     from hipad_amd import functional as HF
     from hipad_amd import lib

@@ -69,8 +69,11 @@ def torch_weights(u, v, keep, L, P, G):
     return w.permute(0, 1, 4, 2, 3, 5)
 
 
-@pytest.mark.parametrize("A,L,P,G,with_keep", [(7, 4, 13, 8, False), (3, 4, 300, 8, True), (5, 2, 9, 4, True)])
+@pytest.mark.parametrize("A,L,P,G,with_keep", [(7, 4, 13, 8, False), (3, 4, 300, 8, True), (5, 2, 9, 4, True),
+                                               (4, 3, 11, 8, True),          # L * G not a power of two
+                                               (1, 3, 30000, 8, True)])      # >= 2^22 logits per anchor: integer-division path
 def test_sampling_weights_fwd_bwd_vs_torch(A, L, P, G, with_keep):
+    """(index arithmetic of the kernels: float-reciprocal quotients below 2^22 logits per anchor, integer division above)"""
     from hipad_amd import functional as HF
     g = torch.Generator().manual_seed(A * P)
     bs, cams, n = 2, 6, L * P * G
