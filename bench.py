@@ -365,7 +365,7 @@ def _daf_grid_threads(A, P, cams=6, bs=1):
 
 
 PMC_FILE = "r03_daf_pmc_traffic.json"
-MFMA_PMC_FILE = "r02a_linear_path_mfma_pmc.json"
+MFMA_PMC_FILE = "r03_linear_path_mfma_pmc.json"
 
 
 def pmc_traffic(kernel, A, P):
@@ -376,8 +376,11 @@ def pmc_traffic(kernel, A, P):
         return None
     with open(path) as f:
         table = json.load(f)["kernels"]
-    if kernel == "daf_bwd_feat_kernel":   # the frame's merged pass: one persistent grid (2048 x 256 threads)
-        hit = table.get("hipad::daf_bwd_feat_kernel grid=524288")
+    if kernel == "frame_pass":            # the frame's merged pass: every kernel of it, each launched once per pass
+        parts = [v for k, v in table.items()
+                 if k.startswith(("hipad::daf_bwd_feat_kernel grid=524288", "hipad::daf_tap_pass_kernel", "hipad::daf_alloc_kernel",
+                                  "hipad::fill_zero_kernel"))]
+        return sum(v["hbm_bytes_per_launch"] for v in parts) if parts else None
     else:
         hit = table.get("hipad::%s grid=%d" % (kernel, _daf_grid_threads(A, P)))
     return None if hit is None else hit["hbm_bytes_per_launch"]
@@ -412,8 +415,8 @@ def roofline_of(daf, layers=6):
         kernel = ("feature-gradient pass of the frame's 24 aggregation calls (hipad_daf_backward_feat_multi: fill, "
                   "daf_tap_pass x2, daf_alloc, daf_bwd_feat_kernel; one pass per frame)")
         extra = dict(rows_touched=daf.rows_touched_frame, kept_pairs=layers * sum(d["kept_pairs"] for d in daf.calls))
-        traffic = pmc_traffic("daf_bwd_feat_kernel", None, None)
-        note_ = "; daf_bwd_feat_kernel only -- the payload kernel of the pass)"
+        traffic = pmc_traffic("frame_pass", None, None)
+        note_ = "; sum over the pass's kernels: fill, count pass, alloc, place pass, accumulate)"
     else:
         dcall = next(d for d in daf.calls if d["name"] == dom[0])
         kname = {"fwd": "daf_fwd_c256_kernel<4, true> (+ combine)", "bwd_lw": "daf_bwd_lw_kernel<4, true, true>"}[dom[1]]
@@ -426,7 +429,7 @@ def roofline_of(daf, layers=6):
     return dict(bound="hbm", kernel=kernel, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                 traffic_source="profiles/" + PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                               "`bench.py --workload daf_stage2`, bytes per launch" + note_,
+                               "tools/pmc_daf_frame.py -- the aggregation path as the step runs it --, bytes per launch" + note_,
                 alg_bytes_per_launch=alg, avg_launch_ms=round(ms, 4), launches_per_frame=1 if dom[0] == "frame" else layers,
                 aggregation_launches=table, **extra)
 

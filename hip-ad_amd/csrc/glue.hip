@@ -213,29 +213,35 @@ __global__ __launch_bounds__(256) void add_rows_kernel(float *__restrict__ out, 
   reinterpret_cast<float4 *>(out)[i] = v;
 }
 
-// out[b, c] = sum over the N rows of x[b, :, c] -- the gradient of a broadcast row vector.  One workgroup per (sample,
-// 64 columns): four row phases of 64 lanes each read coalesced 256-byte rows, partial sums meet in LDS in a fixed
-// order (no atomics: the result does not depend on scheduling).
-__global__ __launch_bounds__(256) void rows_sum_kernel(float *__restrict__ out, const float *__restrict__ x, int N, int C) {
-  __shared__ float part[4][64];
+// out[b, c] = sum over the N rows of x[b, :, c] -- the gradient of a broadcast row vector.  One workgroup of 1024 threads
+// per (sample, 64 columns): sixteen row phases of 64 lanes each read coalesced 256-byte rows, eight loads in flight per
+// thread (480 rows = 4 dependent round trips), partial sums meet in LDS in a fixed order (no atomics: the result does
+// not depend on scheduling).
+__global__ __launch_bounds__(1024) void rows_sum_kernel(float *__restrict__ out, const float *__restrict__ x, int N, int C) {
+  __shared__ float part[16][64];
   const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   const long b = blockIdx.y;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  float s[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s[k] = 0.f;
   if (c < C) {
     const float *xb = x + b * (long)N * C + c;
     int r = ph;
-    for (; r + 12 < N; r += 16) {
-      s0 += xb[(long)r * C];
-      s1 += xb[(long)(r + 4) * C];
-      s2 += xb[(long)(r + 8) * C];
-      s3 += xb[(long)(r + 12) * C];
+    for (; r + 7 * 16 < N; r += 8 * 16) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[k] += xb[(long)(r + 16 * k) * C];
     }
-    for (; r < N; r += 4) s0 += xb[(long)r * C];
+    for (; r < N; r += 16) s[0] += xb[(long)r * C];
   }
-  part[ph][lane] = (s0 + s1) + (s2 + s3);
+  part[ph][lane] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
   __syncthreads();
-  if (ph == 0 && c < C) out[b * C + c] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+  if (ph == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k][lane];
+    out[b * C + c] = t;
+  }
 }
 
 }  // namespace hipad
@@ -324,7 +330,7 @@ int hipad_add_rows(float *out, const float *base, const float *rows0, const floa
 
 int hipad_rows_sum(float *out, const float *x, int bs, int n_rows, int channels, hipad_stream_t stream) {
   if (!out || !x || bs <= 0 || n_rows <= 0 || channels <= 0) return HIPAD_EINVAL;
-  hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)((channels + 63) / 64), (unsigned)bs), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)((channels + 63) / 64), (unsigned)bs), dim3(1024), 0, (hipStream_t)stream,
                      out, x, n_rows, channels);
   return hipGetLastError() == hipSuccess ? HIPAD_OK : HIPAD_ELAUNCH;
 }

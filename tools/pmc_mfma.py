@@ -1,18 +1,24 @@
 """MFMA utilisation of the linear path from one `rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES
-SQ_BUSY_CYCLES GRBM_GUI_ACTIVE` pass of the bench command: per hand-written MFMA kernel the launches, bf16 MFMA flops
-(MOPS x 512), busy fraction of the matrix pipes (MFMA busy cycles / (GRBM_GUI_ACTIVE x 4 SIMDs x 256 CUs / 8 XCDs ...
-see below) and, with a kernel-trace of the same command, the achieved TFLOP/s against the 2.5 PFLOP/s dense bf16 peak.
+SQ_BUSY_CYCLES GRBM_GUI_ACTIVE` pass of the bench command plus a kernel trace of the same command (durations are taken
+from the un-instrumented run: a profiled pass runs at a lower clock).
 
     python tools/pmc_mfma.py <pmc_dir> <trace_dir> <out.json>
 
-MfmaUtil as rocprofv3 defines it for gfx94x/gfx950: SQ_VALU_MFMA_BUSY_CYCLES (summed over the chip) /
-(GRBM_GUI_ACTIVE (max over XCDs) x SIMD_NUM), SIMD_NUM = 256 CUs x 4.
+Counter units (MI355X_MICROARCH.md, "Per-instruction cycle constants" / "DVFS give-back"):
+  SQ_INSTS_VALU_MFMA_MOPS_BF16   512 flops per count, summed over the chip
+  SQ_VALU_MFMA_BUSY_CYCLES       shader cycles a SIMD's matrix pipe is busy, summed over the chip's 1024 SIMDs
+                                 (16 per v_mfma_f32_16x16x32_bf16, 32 per 32x32x16: `busy_cycles_per_16k_flop` checks it)
+  GRBM_GUI_ACTIVE                rocprofv3 reports the SUM over the 8 XCDs: the launch's active cycles are GUI / 8
+so   mfma_util = BUSY / (GUI / 8 x 1024 SIMDs)   and   effective clock = GUI / 8 / duration.
+The two views of one launch agree when  frac_of_2p5PF ~= mfma_util x effective_clock / 2.4 GHz  (2.5 PFLOP/s is 1024
+SIMDs x 16384 flop / 16 cycles at 2.4 GHz); `self_consistency` is the ratio of the two sides (1.0 = agree; the round-2
+table divided by GUI instead of GUI / 8 and read 8x low).
 """
 import collections, csv, glob, json, sys
 
 SIMDS = 256 * 4
 PEAK_TFLOPS = 2500.0
-KERNELS = ("hipad::gemm_kernel", "hipad::linear_bwd_fused_kernel", "hipad::chain_fwd_kernel", "hipad::chain_bwd_kernel",
+KERNELS = ("hipad::gemm_kernel", "hipad::gemm_fwd_hilo_kernel", "hipad::linear_bwd_fused_kernel", "hipad::chain_fwd_kernel", "hipad::chain_bwd_kernel",
            "hipad::chain_dw_kernel", "hipad::attn_fwd_kernel", "hipad::attn_bwd_dq_kernel", "hipad::attn_bwd_dkv_kernel")
 
 
@@ -45,12 +51,20 @@ for k, c in sorted(vals.items()):
     busy = sum(c.get("SQ_VALU_MFMA_BUSY_CYCLES", [0])) / n
     gui = sum(c.get("GRBM_GUI_ACTIVE", [0])) / n
     us = sum(dur[k]) / len(dur[k]) if dur.get(k) else None
+    mfma16k = flops / 16384.0                       # MFMA instructions, in units of a 16x16x32 bf16 one
+    util = busy / (gui / 8.0 * SIMDS) if gui else None
+    clock = gui / 8.0 / (us * 1e-6) / 1e9 if (gui and us) else None
+    frac = None if not us else flops / (us * 1e-6) / 1e12 / PEAK_TFLOPS
     out[k] = dict(launches_profiled=n, mfma_gflop_per_launch=round(flops / 1e9, 4),
-                  mfma_util_pct=round(100.0 * busy / (gui * SIMDS), 3) if gui else None,
+                  busy_cycles_per_16k_flop=round(busy / mfma16k, 2) if mfma16k else None,
+                  mfma_util_pct=round(100.0 * util, 3) if util is not None else None,
+                  effective_clock_GHz=None if clock is None else round(clock, 3),
                   avg_us=None if us is None else round(us, 2),
                   achieved_tflops=None if not us else round(flops / (us * 1e-6) / 1e12, 2),
-                  frac_of_2p5PF=None if not us else round(flops / (us * 1e-6) / 1e12 / PEAK_TFLOPS, 5))
+                  frac_of_2p5PF=None if frac is None else round(frac, 5),
+                  self_consistency=None if not (util and clock and frac) else round(frac / (util * clock / 2.4), 3))
 json.dump(dict(note="per launch averages; MFMA flops = SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512; util = SQ_VALU_MFMA_BUSY_CYCLES / "
-                    "(GRBM_GUI_ACTIVE x 1024 SIMDs); durations from the un-instrumented kernel trace of the same command",
+                    "(GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); effective clock = GUI / 8 / duration; durations from the "
+                    "un-instrumented kernel trace of the same command; self_consistency = frac_of_2p5PF / (util x clock / 2.4 GHz)",
                kernels=out), open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
