@@ -204,27 +204,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(float *__restrict__ out, 
 }
 
 // =====================================================================================
-// backward helpers: delta[b,h,q] = sum_d dO * O
-// =====================================================================================
-__global__ __launch_bounds__(256) void attn_delta_kernel(float *__restrict__ delta, const float *__restrict__ dout,
-                                                         const float *__restrict__ out, int B, int H, int Nq, int D) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (b, q, h)
-  if (i >= (long)B * Nq * H) return;
-  const int h = (int)(i % H);
-  const long bq = i / H;
-  const int qi = (int)(bq % Nq);
-  const long b = bq / Nq;
-  const float *d = dout + bq * H * D + h * D;
-  const float *o = out + bq * H * D + h * D;
-  float acc = 0.f;
-  for (int j = 0; j < D; j += 4) {
-    const float4 x = *reinterpret_cast<const float4 *>(d + j), y = *reinterpret_cast<const float4 *>(o + j);
-    acc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
-  }
-  delta[(b * H + h) * Nq + qi] = acc;
-}
-
-// =====================================================================================
 // backward dQ: workgroup = 16 queries of one (b, h); waves split the keys.
 //   S^T, P^T as in forward; dP^T = V dO^T (keys x queries); dS^T = P^T o (dP^T - delta) * scale
 //   dQ^T[d][query] += K^T[d][key] dS^T[key][query]
@@ -233,7 +212,8 @@ template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(float *__restrict__ dq, const float *__restrict__ dout,
                                                           const float *__restrict__ q, const float *__restrict__ k,
                                                           const float *__restrict__ v, const float *__restrict__ lse,
-                                                          const float *__restrict__ delta, AttnArgs a) {
+                                                          const float *__restrict__ out, float *__restrict__ delta,
+                                                          AttnArgs a) {
   constexpr int DC32 = D / 32, DC16 = D / 16;
   __shared__ float s_o[4][64][DC16 * 4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -246,7 +226,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(float *__restrict__ dq
   const float *kb = k + (size_t)b * a.Nk * a.ld + h * D;
   const float *vb = v + (size_t)b * a.Nk * a.ld + h * D;
   const float my_lse = lse[((size_t)b * a.H + h) * a.Nq + qi];
-  const float my_delta = delta[((size_t)b * a.H + h) * a.Nq + qi];
+  // delta[b, h, q] = sum_d dO * O in fp32, computed here (a lane holds 8 columns per 32-column chunk of its query, the
+  // four quads cover the row) and left in `delta` for the dK / dV kernel that follows on the stream: no separate launch
+  const float *op = out + ((size_t)b * a.Nq + qi) * a.ld + h * D;
+  float my_delta = 0.f;
+#pragma unroll
+  for (int c = 0; c < DC32; ++c) {
+    const float4 d0 = *reinterpret_cast<const float4 *>(dop + 32 * c + 8 * quad);
+    const float4 d1 = *reinterpret_cast<const float4 *>(dop + 32 * c + 8 * quad + 4);
+    const float4 o0 = *reinterpret_cast<const float4 *>(op + 32 * c + 8 * quad);
+    const float4 o1 = *reinterpret_cast<const float4 *>(op + 32 * c + 8 * quad + 4);
+    my_delta += (d0.x * o0.x + d0.y * o0.y + d0.z * o0.z + d0.w * o0.w) + (d1.x * o1.x + d1.y * o1.y + d1.z * o1.z + d1.w * o1.w);
+  }
+  my_delta += __shfl_xor(my_delta, 16);
+  my_delta += __shfl_xor(my_delta, 32);
+  if (wv == 0 && quad == 0 && q0 + l15 < a.Nq) delta[((size_t)b * a.H + h) * a.Nq + qi] = my_delta;
 
   bf16x8 qf[DC32], dof[DC32];
 #pragma unroll
@@ -483,12 +477,9 @@ int hipad_attention_backward(float *dq, float *dk, float *dv, float *delta_ws, c
   if (!dq || !dk || !dv || !delta_ws || !dout || !out || !lse || !q || !k || !v) return HIPAD_EINVAL;
   const AttnArgs a = make_args(B, H, Nq, Nk, D, softmax_scale, p_drop, seed, seed_dev);
   hipStream_t stream = (hipStream_t)stream_;
-  const long nd = (long)B * Nq * H;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, stream, delta_ws, dout, out,
-                     B, H, Nq, D);
   const dim3 gq((Nq + 15) / 16, H, B), gk((Nk + 15) / 16, H, B), block(256);
 #define HIPAD_ATTN_BWD(DD)                                                                                   \
-  hipLaunchKernelGGL(attn_bwd_dq_kernel<DD>, gq, block, 0, stream, dq, dout, q, k, v, lse, (const float *)delta_ws, a); \
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<DD>, gq, block, 0, stream, dq, dout, q, k, v, lse, out, delta_ws, a);           \
   hipLaunchKernelGGL(attn_bwd_dkv_kernel<DD>, gk, block, 0, stream, dk, dv, dout, q, k, v, lse, (const float *)delta_ws, a)
   if (D == 32) { HIPAD_ATTN_BWD(32); }
   else if (D == 64) { HIPAD_ATTN_BWD(64); }

@@ -724,6 +724,10 @@ def motion_query_embed(cls, box, table, freq, sin_col, cos_col):
     return out
 
 
+class HipadLayoutError(HipadError):
+    """An argument layout a kernel does not take, found on the host BEFORE anything was launched."""
+
+
 class AccItem(ctypes.Structure):
     _fields_ = [("dst", c_void_p), ("src", c_void_p), ("sizes", ctypes.c_int32 * 4), ("strides", ctypes.c_int32 * 4)]
 
@@ -739,11 +743,18 @@ def accumulate_bf16(pairs):
     dev = pairs[0][0].device
     items = []
     for dst, src in pairs:
-        _req(dst, torch.float32, "dst")
+        try:
+            _req(dst, torch.float32, "dst")
+        except HipadError as e:
+            raise HipadLayoutError(str(e)) from None
         if not src.is_cuda or src.dtype != torch.bfloat16 or src.device != dev or dst.device != dev:
-            raise HipadError("accumulate_bf16: src must be a bf16 tensor on dst's device")
+            raise HipadLayoutError("accumulate_bf16: src must be a bf16 tensor on dst's device")
         if src.shape != dst.shape or src.dim() > 4 or src.numel() == 0:
-            raise HipadError(f"accumulate_bf16: shapes {tuple(dst.shape)} / {tuple(src.shape)} (need equal, <= 4-D, non-empty)")
+            raise HipadLayoutError(f"accumulate_bf16: shapes {tuple(dst.shape)} / {tuple(src.shape)} (need equal, <= 4-D, non-empty)")
+        # the kernel trusts the strides: the furthest element they reach must lie inside the source's storage
+        last = src.storage_offset() + sum((n - 1) * st for n, st in zip(src.shape, src.stride()))
+        if any(st < 0 for st in src.stride()) or last * 2 >= src.untyped_storage().nbytes():
+            raise HipadLayoutError("accumulate_bf16: source strides reach outside its storage")
         pad = 4 - src.dim()
         it = AccItem()
         it.dst, it.src = dst.data_ptr(), src.data_ptr()

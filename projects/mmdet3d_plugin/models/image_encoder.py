@@ -94,7 +94,13 @@ def _flush_weight_grads():
     for tgt, g in pairs:
         by_dev.setdefault(tgt.device, []).append((tgt, g))
     for dev_pairs in by_dev.values():
-        _lib.accumulate_bf16(dev_pairs)
+        try:
+            _lib.accumulate_bf16(dev_pairs)
+        except _lib.HipadLayoutError:
+            # a gradient layout the table kernel does not take (found on the host before any launch): one add per
+            # tensor, as without batching
+            for tgt, g in dev_pairs:
+                tgt.add_(g)
 
 
 class Conv2d(nn.Conv2d):

@@ -134,12 +134,20 @@ def test_config4_stage2_bs2():
                     continue
                 for b in range(2):
                     ref = singles[b][ti][key][li][0]
-                    err = float((t[b] - ref).abs().max() / ref.abs().max().clamp_min(1e-9))
+                    scale = ref.abs().max().clamp_min(1e-9)
+                    err = float((t[b] - ref).abs().max() / scale)
                     # fp32 encoder, bf16-operand decoder: the fp32 convolutions of 12 and of 6 images differ in the last
                     # bits, the decoder's operand rounding turns that into <= 1.6e-3 by the last layer (measured); a
-                    # sample reading another sample's rows is an O(1) error
-                    # (the motion head sees sin / cos of metres x 10000^(i/128) phases of the predicted boxes: the same noise
-                    # reaches 1.3e-2 .. 8.6e-2 there, cf. tests/test_decoder.py; it is held to "not another sample's rows")
-                    assert err < (0.25 if ti == 4 else 5e-3), (ti, key, li, b, err)
+                    # sample reading another sample's rows is an O(1) error on EVERY instance
+                    if ti != 4:
+                        assert err < 5e-3, (ti, key, li, b, err)
+                    else:
+                        # the motion head's queries are the mode anchors of each box's ARG-MAX class turned by its yaw and
+                        # passed through sin / cos of metres x 10000^(i/128): last-bit noise flips the class of a few
+                        # near-tie boxes (another anchor set: O(1) on that box, 0.30 seen) and reaches 1e-2 .. 9e-2
+                        # elsewhere.  Held per instance: the typical box agrees, few are off at all.
+                        per_box = (t[b] - ref).abs().flatten(1).amax(1) / scale
+                        assert float(per_box.median()) < 5e-3, (key, li, b, float(per_box.median()))
+                        assert float((per_box > 0.1).float().mean()) < 0.02, (key, li, b, float((per_box > 0.1).float().mean()))
                     checked += 1
     assert checked >= 100
