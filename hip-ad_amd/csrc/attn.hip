@@ -47,6 +47,46 @@ __device__ __forceinline__ bf16x8 load8(const float *p, float mul) {
   return r;
 }
 
+// Transposed operand tiles of the backward kernels.  dK / dV / dQ contract over the 32 rows (queries or keys) of a step,
+// so one MFMA operand is a COLUMN of Q, dO or K across 8 of those rows: read from global that is 8 scalar loads per
+// operand (64 of them per step of the dK / dV kernel at D = 64, each with its own address arithmetic and conversion).
+// Instead a wave stages the step's 32 x D tile once -- coalesced float4 loads, bf16 pairs of two adjacent rows written
+// as one dword -- into a private LDS tile stored column-major, and every operand becomes two 8-byte LDS reads.
+// Row order, rounding and accumulation order are unchanged: the results are bit-identical to the scalar-load form.
+constexpr int kTS = 36;  // bf16 per tile row: 32 rows of the step + pad (rows stay 8-byte aligned)
+
+template <int D>
+__device__ __forceinline__ void stage_transposed(short (*tile)[kTS], const float *base, int row0, int nrows, int ld,
+                                                 int lane) {
+  constexpr int C4 = D / 4;                 // float4 per row
+  constexpr int ITEMS = 16 * C4 / 64;       // (row pair, float4) items per lane
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int idx = lane + 64 * i;
+    const int rp = idx / C4, c4 = idx - rp * C4;
+    const int r0 = min(row0 + 2 * rp, nrows - 1), r1 = min(row0 + 2 * rp + 1, nrows - 1);
+    const float4 a = *reinterpret_cast<const float4 *>(base + (size_t)r0 * ld + 4 * c4);
+    const float4 b = *reinterpret_cast<const float4 *>(base + (size_t)r1 * ld + 4 * c4);
+    const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned lo = (unsigned short)f2bf(av[e]), hi = (unsigned short)f2bf(bv[e]);
+      *reinterpret_cast<unsigned *>(&tile[4 * c4 + e][2 * rp]) = lo | (hi << 16);
+    }
+  }
+}
+
+// operand of lane (l15, quad) for column `col`: rows 4 quad .. 4 quad + 3 and 16 + 4 quad .. 16 + 4 quad + 3 of the step
+__device__ __forceinline__ bf16x8 tile_operand(const short (*tile)[kTS], int col, int quad) {
+  using s4 = __attribute__((ext_vector_type(4))) short;
+  const s4 lo = *reinterpret_cast<const s4 *>(&tile[col][4 * quad]);
+  const s4 hi = *reinterpret_cast<const s4 *>(&tile[col][16 + 4 * quad]);
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
 // counter-based keep decision for attention dropout: same (seed, b, h, q, k) -> same bit in fwd/bwd
 __device__ __forceinline__ bool keep_prob(uint32_t seed, int b, int h, int q, int k, uint32_t thresh) {
   uint32_t x = seed ^ (uint32_t)(b * 0x9E3779B1u) ^ (uint32_t)(h * 0x85EBCA77u);
@@ -82,8 +122,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(float *__restrict__ out, 
                                                        const float *__restrict__ v, AttnArgs a) {
   constexpr int DC32 = D / 32;  // 32-wide d chunks (QK reduction)
   constexpr int DC16 = D / 16;  // 16-wide d chunks (O rows)
+  // V tile of the step transposed in LDS (stage_transposed above): measured in the replayed step 15.2 -> 13.2 us at
+  // D = 32 but 20.4 -> 21.6 us at D = 64 (the scalar loads overlap the S tiles' MFMAs; the staged path adds an LDS round
+  // trip to every step) -- off, the dK / dV kernel is where it pays
+  constexpr bool kStage = false;
+  constexpr int kEpiBytes = 4 * 64 * DC16 * 4 * 4, kTileBytes = kStage ? 4 * D * kTS * 2 : 0;
   __shared__ float s_m[4][16], s_l[4][16];
-  __shared__ float s_o[4][64][DC16 * 4];
+  __shared__ __attribute__((aligned(16))) unsigned char raw[kEpiBytes > kTileBytes ? kEpiBytes : kTileBytes];
+  float (*s_o)[64][DC16 * 4] = reinterpret_cast<float (*)[64][DC16 * 4]>(raw);
+  short (*t_v)[D][kTS] = reinterpret_cast<short (*)[D][kTS]>(raw);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t seed = a.drop_thresh ? eff_seed(a) : 0u;
   const int l15 = lane & 15, quad = lane >> 4;
@@ -105,6 +152,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(float *__restrict__ out, 
   const int nsteps = (a.Nk + 31) / 32;
   for (int step = wv; step < nsteps; step += 4) {
     const int k0 = step * 32;
+    if (kStage) {
+      __builtin_amdgcn_wave_barrier();
+      stage_transposed<D>(t_v[wv], vb, k0, a.Nk, a.ld, lane);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
     // S^T tiles: rows = keys k0 + 16t + 4*quad + r, col = query l15
     f32x4 s[2];
 #pragma unroll
@@ -150,10 +203,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(float *__restrict__ out, 
 #pragma unroll
     for (int c = 0; c < DC16; ++c) {
       bf16x8 vf;
+      if (kStage) {
+        vf = tile_operand(t_v[wv], 16 * c + l15, quad);
+      } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int key = min(k0 + 16 * (j >> 2) + 4 * quad + (j & 3), a.Nk - 1);
-        vf[j] = f2bf(vb[(size_t)key * a.ld + 16 * c + l15]);
+        for (int j = 0; j < 8; ++j) {
+          const int key = min(k0 + 16 * (j >> 2) + 4 * quad + (j & 3), a.Nk - 1);
+          vf[j] = f2bf(vb[(size_t)key * a.ld + 16 * c + l15]);
+        }
       }
       o[c] = o[c] * alpha;
       o[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[c], 0, 0, 0);
@@ -162,6 +219,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(float *__restrict__ out, 
   // row sum over the four quads of a query
   l += __shfl_xor(l, 16);
   l += __shfl_xor(l, 32);
+  if (kStage) __syncthreads();              // the V tiles and the merge buffer share LDS
   // ---- merge the 4 waves
   if (quad == 0) {
     s_m[wv][l15] = m;
@@ -215,7 +273,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(float *__restrict__ dq
                                                           const float *__restrict__ out, float *__restrict__ delta,
                                                           AttnArgs a) {
   constexpr int DC32 = D / 32, DC16 = D / 16;
-  __shared__ float s_o[4][64][DC16 * 4];
+  // K tile of the step transposed in LDS: 37.0 -> 36.4 us at D = 64, 17.2 -> 24.5 us at D = 32 (with the delta sum
+  // folded in at the same time) -- off
+  constexpr bool kStage = false;
+  constexpr int kEpiBytes = 4 * 64 * DC16 * 4 * 4, kTileBytes = kStage ? 4 * D * kTS * 2 : 0;
+  __shared__ __attribute__((aligned(16))) unsigned char raw[kEpiBytes > kTileBytes ? kEpiBytes : kTileBytes];
+  float (*s_o)[64][DC16 * 4] = reinterpret_cast<float (*)[64][DC16 * 4]>(raw);   // epilogue: the waves' partial dQ
+  short (*t_k)[D][kTS] = reinterpret_cast<short (*)[D][kTS]>(raw);               // main loop: K tile per wave, transposed
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t seed = a.drop_thresh ? eff_seed(a) : 0u;
   const int l15 = lane & 15, quad = lane >> 4;
@@ -255,6 +319,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(float *__restrict__ dq
   const int nsteps = (a.Nk + 31) / 32;
   for (int step = wv; step < nsteps; step += 4) {
     const int k0 = step * 32;
+    if (kStage) {
+      __builtin_amdgcn_wave_barrier();      // the previous step's operand reads are done
+      stage_transposed<D>(t_k[wv], kb, k0, a.Nk, a.ld, lane);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
     bf16x8 dsf;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -282,14 +352,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(float *__restrict__ dq
 #pragma unroll
     for (int c = 0; c < DC16; ++c) {
       bf16x8 kf;
+      if (kStage) {
+        kf = tile_operand(t_k[wv], 16 * c + l15, quad);
+      } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int key = min(k0 + 16 * (j >> 2) + 4 * quad + (j & 3), a.Nk - 1);
-        kf[j] = f2bf(kb[(size_t)key * a.ld + 16 * c + l15]);
+        for (int j = 0; j < 8; ++j) {
+          const int key = min(k0 + 16 * (j >> 2) + 4 * quad + (j & 3), a.Nk - 1);
+          kf[j] = f2bf(kb[(size_t)key * a.ld + 16 * c + l15]);
+        }
       }
       acc_dq[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsf, acc_dq[c], 0, 0, 0);
     }
   }
+  if (kStage) __syncthreads();              // the tiles and the epilogue buffer share LDS
 #pragma unroll
   for (int c = 0; c < DC16; ++c)
 #pragma unroll
@@ -322,8 +397,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(float *__restrict__ d
                                                            const float *__restrict__ lse,
                                                            const float *__restrict__ delta, AttnArgs a) {
   constexpr int DC32 = D / 32, DC16 = D / 16;
-  __shared__ float s_k[4][64][DC16 * 4];
-  __shared__ float s_v[4][64][DC16 * 4];
+  // Q and dO tiles of the step transposed in LDS: 56.6 -> 51.5 us at D = 64, 20.7 -> 19.7 us at D = 32 (64 scalar loads
+  // per step before); a 128-wide head's tiles do not fit: scalar loads there
+  constexpr bool kStage = D <= 64;
+  constexpr int kEpiBytes = 2 * 4 * 64 * DC16 * 4 * 4, kTileBytes = kStage ? 2 * 4 * D * kTS * 2 : 0;
+  __shared__ __attribute__((aligned(16))) unsigned char raw[kEpiBytes > kTileBytes ? kEpiBytes : kTileBytes];
+  float (*s_k)[64][DC16 * 4] = reinterpret_cast<float (*)[64][DC16 * 4]>(raw);   // epilogue: the waves' partial dK, dV
+  float (*s_v)[64][DC16 * 4] = s_k + 4;
+  short (*t_q)[D][kTS] = reinterpret_cast<short (*)[D][kTS]>(raw);               // main loop: Q and dO tiles per wave
+  short (*t_do)[D][kTS] = t_q + 4;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t seed = a.drop_thresh ? eff_seed(a) : 0u;
   const int l15 = lane & 15, quad = lane >> 4;
@@ -352,6 +434,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(float *__restrict__ d
   const int nsteps = (a.Nq + 31) / 32;
   for (int step = wv; step < nsteps; step += 4) {
     const int qq0 = step * 32;
+    if (kStage) {
+      __builtin_amdgcn_wave_barrier();
+      stage_transposed<D>(t_q[wv], qb, qq0, a.Nq, a.ld, lane);
+      stage_transposed<D>(t_do[wv], dob, qq0, a.Nq, a.ld, lane);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
     bf16x8 pf, dsf;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -383,16 +472,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(float *__restrict__ d
 #pragma unroll
     for (int c = 0; c < DC16; ++c) {
       bf16x8 dot, qt;  // A operands: [row = d][k = query slot j]
+      if (kStage) {
+        dot = tile_operand(t_do[wv], 16 * c + l15, quad);
+        qt = tile_operand(t_q[wv], 16 * c + l15, quad);
+      } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int qi = min(qq0 + 16 * (j >> 2) + 4 * quad + (j & 3), a.Nq - 1);
-        dot[j] = f2bf(dob[(size_t)qi * a.ld + 16 * c + l15]);
-        qt[j] = f2bf(qb[(size_t)qi * a.ld + 16 * c + l15]);
+        for (int j = 0; j < 8; ++j) {
+          const int qi = min(qq0 + 16 * (j >> 2) + 4 * quad + (j & 3), a.Nq - 1);
+          dot[j] = f2bf(dob[(size_t)qi * a.ld + 16 * c + l15]);
+          qt[j] = f2bf(qb[(size_t)qi * a.ld + 16 * c + l15]);
+        }
       }
       acc_v[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pf, acc_v[c], 0, 0, 0);
       acc_k[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsf, acc_k[c], 0, 0, 0);
     }
   }
+  if (kStage) __syncthreads();              // the tiles and the epilogue buffers share LDS
 #pragma unroll
   for (int c = 0; c < DC16; ++c)
 #pragma unroll
