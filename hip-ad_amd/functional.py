@@ -604,6 +604,72 @@ def add_rows(base, *rows):
     return _AddRows.apply(base, *rows)
 
 
+class _DepthLoss(Function):
+    """Dense-depth heads + loss on the flat pyramid (csrc/depthloss.hip).  Inputs: the pyramid (the alias
+    shared_feature_grad returned, so that the feature gradient goes into the frame's shared fp32 buffer), its token,
+    focal, then per level (gt, weight, bias)."""
+
+    @staticmethod
+    def forward(ctx, feat, token, focal, meta, *tensors):
+        cams, geometry, equal_focal, max_depth, loss_weight = meta        # geometry: [(rows_per_cam, row_offset)]
+        L = len(geometry)
+        gts = [_c32(t).reshape(-1) for t in tensors[:L]]
+        ws, bs_ = tensors[L:2 * L], tensors[2 * L:3 * L]
+        levels = [(gts[i], ws[i].detach().reshape(-1), bs_[i].detach().reshape(-1), geometry[i][0], geometry[i][1]) for i in range(L)]
+        focal = None if focal is None else _c32(focal).reshape(-1)
+        loss, coef, pred = _lib.depth_loss_forward(feat, focal, levels, cams, equal_focal, max_depth, loss_weight)
+        ctx.holder = getattr(feat, "_hipad_grad_holder", None) if token is not None else None
+        ctx.meta, ctx.levels, ctx.params = meta, levels, (ws, bs_)
+        ctx.save_for_backward(feat, pred, coef)
+        ctx.terms = loss.detach()
+        return loss[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        feat, pred, coef = ctx.saved_tensors
+        cams, geometry, _, max_depth, _ = ctx.meta
+        L = len(geometry)
+        ws, bs_ = ctx.params
+        grads, rets = [], [None] * (3 * L)
+        for i in range(L):
+            pair = []
+            for k, p in ((L + i, ws[i]), (2 * L + i, bs_[i])):
+                tgt = None
+                if ctx.needs_input_grad[4 + k]:
+                    gp = p.grad if (LINEAR_INPLACE_GRAD and p.is_leaf) else None
+                    if gp is not None and gp.is_contiguous() and gp.dtype == torch.float32:
+                        INPLACE_PARAMS.add(id(p))
+                        tgt = gp
+                    else:
+                        tgt = rets[k] = torch.zeros_like(p, dtype=torch.float32)
+                pair.append(tgt)
+            grads.append(tuple(pair))
+        grad_token = ret_feat = None
+        if ctx.holder is not None:
+            # the frame's shared pyramid gradient (the aggregation calls' buffer): created here if this node runs first
+            key = torch.cuda.current_stream(feat.device).cuda_stream
+            buf = ctx.holder["bufs"].get(key)
+            if buf is None:
+                buf = ctx.holder["bufs"][key] = torch.zeros(feat.shape, dtype=torch.float32, device=feat.device)
+            grad_token = ctx.holder.get("zero")
+            if grad_token is None:
+                grad_token = torch.zeros((), dtype=feat.dtype, device=feat.device)
+        else:
+            buf = ret_feat = torch.zeros(feat.shape, dtype=torch.float32, device=feat.device)
+        _lib.depth_loss_backward(buf, pred, coef, _c32(g).reshape(-1), feat, ctx.levels, grads, cams, max_depth)
+        return (ret_feat, grad_token, None, None) + tuple(rets)
+
+
+def depth_loss(feat, focal, gts, weights, biases, geometry, cams, equal_focal, max_depth, loss_weight):
+    """Masked-L1 dense-depth loss of the 1x1 heads (``weights[l]`` (1, 256, 1, 1), ``biases[l]`` (1,)) on the rows of
+    the flat bf16 pyramid ``feat`` (bs, rows, 256); ``geometry[l]`` = (rows per camera, first row of the level inside a
+    sample); ``gts[l]``: (bs * cams, h, w).  One launch forward (+ a one-thread finish), one backward."""
+    token = getattr(feat, "_hipad_grad_token", None)
+    meta = (int(cams), tuple((int(a), int(b)) for a, b in geometry), float(equal_focal), float(max_depth), float(loss_weight))
+    return _DepthLoss.apply(feat, token, focal, meta, *gts, *weights, *biases)
+
+
 class _StepOffsets(Function):
     @staticmethod
     def forward(ctx, x):

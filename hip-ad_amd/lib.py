@@ -75,6 +75,10 @@ SIGNATURES = {
                                                                       c_void_p]),
     "hipad_motion_query_embed": (c_int, [c_void_p] * 5 + [ctypes.c_longlong] + [c_int] * 7 + [c_void_p]),
     "hipad_accumulate_bf16": (c_int, [c_void_p, c_int, c_void_p]),
+    "hipad_depth_loss_workspace": (c_size_t, []),
+    "hipad_depth_loss_forward": (c_int, [c_void_p] * 4 + [c_size_t, c_void_p, ctypes.c_longlong, c_void_p, c_void_p]
+                                 + [c_int] * 3 + [ctypes.c_float] * 3 + [c_void_p]),
+    "hipad_depth_loss_backward": (c_int, [c_void_p] * 5 + [ctypes.c_longlong, c_void_p] + [c_int] * 3 + [ctypes.c_float, c_void_p]),
     "hipad_add_rows": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),
     "hipad_rows_sum": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p]),
     "hipad_step_offsets": (c_int, [c_void_p] * 2 + [ctypes.c_longlong] + [c_int] * 3 + [c_void_p]),
@@ -95,6 +99,10 @@ _lib = None
 
 class HipadError(RuntimeError):
     pass
+
+
+class HipadLayoutError(HipadError):
+    """An argument layout a kernel does not take, found on the host BEFORE anything was launched."""
 
 
 def load():
@@ -724,8 +732,81 @@ def motion_query_embed(cls, box, table, freq, sin_col, cos_col):
     return out
 
 
-class HipadLayoutError(HipadError):
-    """An argument layout a kernel does not take, found on the host BEFORE anything was launched."""
+class DepthLevel(ctypes.Structure):
+    _fields_ = [("gt", c_void_p), ("weight", c_void_p), ("bias", c_void_p), ("grad_weight", c_void_p), ("grad_bias", c_void_p),
+                ("rows_per_cam", ctypes.c_int32), ("row_offset", ctypes.c_int32)]
+
+
+DEPTH_MAX_LEVELS = 4
+
+
+def _depth_levels(feat, levels, cams, grads=None):
+    """levels: [(gt fp32, weight fp32 (256 values), bias fp32 (1 value), rows_per_cam, row_offset)] -> ctypes array."""
+    if feat.dim() != 3 or feat.shape[-1] != 256 or feat.dtype != torch.bfloat16 or not feat.is_cuda or not feat.is_contiguous():
+        raise HipadLayoutError("depth_loss: feat must be a contiguous bf16 CUDA tensor (bs, rows, 256)")
+    if not 1 <= len(levels) <= DEPTH_MAX_LEVELS:
+        raise HipadLayoutError(f"depth_loss: 1..{DEPTH_MAX_LEVELS} levels")
+    bs = feat.shape[0]
+    arr = (DepthLevel * len(levels))()
+    for i, (gt, w, b, rpc, off) in enumerate(levels):
+        for t, n, numel in ((gt, "gt", bs * cams * rpc), (w, "weight", 256), (b, "bias", 1)):
+            _req(t, torch.float32, f"level {i} {n}")
+            if t.numel() != numel:
+                raise HipadLayoutError(f"depth_loss: level {i} {n} has {t.numel()} elements, expected {numel}")
+        if off < 0 or off + cams * rpc > feat.shape[1]:
+            raise HipadLayoutError(f"depth_loss: level {i} rows [{off}, {off + cams * rpc}) outside the pyramid")
+        a = arr[i]
+        a.gt, a.weight, a.bias = gt.data_ptr(), w.data_ptr(), b.data_ptr()
+        a.rows_per_cam, a.row_offset = int(rpc), int(off)
+        if grads is not None:
+            gw, gb = grads[i]
+            for t, n, numel in ((gw, "grad_weight", 256), (gb, "grad_bias", 1)):
+                if t is not None:
+                    _req(t, torch.float32, f"level {i} {n}")
+                    if t.numel() != numel:
+                        raise HipadLayoutError(f"depth_loss: level {i} {n} has {t.numel()} elements, expected {numel}")
+            a.grad_weight, a.grad_bias = _ptr(gw), _ptr(gb)
+    return arr
+
+
+def depth_loss_forward(feat, focal, levels, cams, equal_focal, max_depth, loss_weight):
+    """-> (loss (1 + L,): total then per level, coef (4,), pred (rows of all levels,)); see include/hipad.h."""
+    lib = load()
+    arr = _depth_levels(feat, levels, cams)
+    bs = feat.shape[0]
+    if focal is not None:
+        _req(focal, torch.float32, "focal")
+        if focal.numel() != bs * cams:
+            raise HipadLayoutError("depth_loss: focal must hold bs * cams values")
+    dev = feat.device
+    total = sum(bs * cams * lv[3] for lv in levels)
+    loss = torch.empty(1 + len(levels), dtype=torch.float32, device=dev)
+    coef = torch.empty(DEPTH_MAX_LEVELS, dtype=torch.float32, device=dev)
+    pred = torch.empty(total, dtype=torch.float32, device=dev)
+    ws = torch.empty(lib.hipad_depth_loss_workspace() // 8, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.hipad_depth_loss_forward(loss.data_ptr(), coef.data_ptr(), pred.data_ptr(), ws.data_ptr(), ws.numel() * 8,
+                                           feat.data_ptr(), feat.shape[1], _ptr(focal), arr, len(levels), bs, cams,
+                                           float(equal_focal), float(max_depth), float(loss_weight), stream_ptr(dev)),
+              "hipad_depth_loss_forward")
+    return loss, coef, pred
+
+
+def depth_loss_backward(grad_feat, pred, coef, upstream, feat, levels, grads, cams, max_depth):
+    """grad_feat (bs, rows, 256) fp32 += the loss's feature gradient; grads: [(grad_weight or None, grad_bias or None)]."""
+    lib = load()
+    arr = _depth_levels(feat, levels, cams, grads)
+    _req(grad_feat, torch.float32, "grad_feat")
+    if grad_feat.shape != feat.shape:
+        raise HipadLayoutError("depth_loss: grad_feat must have the pyramid's shape")
+    for t, n in ((pred, "pred"), (coef, "coef")):
+        _req(t, torch.float32, n)
+    if upstream is not None:
+        _req(upstream, torch.float32, "upstream")
+    with torch.cuda.device(feat.device):
+        check(lib.hipad_depth_loss_backward(grad_feat.data_ptr(), pred.data_ptr(), coef.data_ptr(), _ptr(upstream), feat.data_ptr(),
+                                            feat.shape[1], arr, len(levels), feat.shape[0], cams, float(max_depth),
+                                            stream_ptr(feat.device)), "hipad_depth_loss_backward")
 
 
 class AccItem(ctypes.Structure):

@@ -657,6 +657,40 @@ int hipad_rows_sum(float *out, const float *x, int bs, int n_rows, int channels,
 int hipad_step_offsets(float *out, const float *x, long long rows, int steps, int dims, int adjoint, hipad_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Dense-depth heads + loss on the flat pyramid (hip-ad_amd/csrc/depthloss.hip).  Replaces: DenseDepthNet.forward and
+ * .loss (reference models/blocks.py:266-326) in training: per level a 1x1 convolution 256 -> 1 on the fp32-widened
+ * level, exp, x focal / equal_focal, masked L1 against the sparse LiDAR depth, normalised per level by
+ * max(1, n_valid * num_levels).
+ *   feat: the frame's flat bf16 pyramid (bs, pyramid_rows, 256); level l occupies rows [row_offset, row_offset + cams *
+ *   rows_per_cam) of every sample, camera-major (the layout the aggregation op reads).  gt: (bs * cams * rows_per_cam)
+ *   fp32 per level, <= 0 = no target.  weight: 256 fp32, bias: 1 fp32.  focal: bs * cams or NULL.
+ * forward: loss[0] = total, loss[1 + l] = the level's term; coef[l] and pred (one float per row of all levels, level
+ *   after level) are kept for the backward; workspace: hipad_depth_loss_workspace() bytes, 8-byte aligned.  The error
+ *   sums are 64-bit fixed-point integers: the value does not depend on the order of the atomics.
+ * backward: grad_feat (bs, pyramid_rows, 256) fp32 += d loss / d feat (rows with a valid target only; plain
+ *   read-modify-write: nothing else may write grad_feat concurrently); grad_weight / grad_bias of every level (may be
+ *   NULL) += their gradients (fp32 atomics).  upstream: device scalar d total / d loss (NULL = 1).
+ * ---------------------------------------------------------------------------------- */
+#define HIPAD_DEPTH_MAX_LEVELS 4
+typedef struct hipad_depth_level {
+  const float *gt;
+  const float *weight;
+  const float *bias;
+  float *grad_weight;
+  float *grad_bias;
+  int32_t rows_per_cam;
+  int32_t row_offset;
+} hipad_depth_level;
+size_t hipad_depth_loss_workspace(void);
+int hipad_depth_loss_forward(float *loss, float *coef, float *pred, void *workspace, size_t workspace_bytes,
+                             const unsigned short *feat, long long pyramid_rows, const float *focal,
+                             const hipad_depth_level *levels, int nlevels, int bs, int cams, float equal_focal,
+                             float max_depth, float loss_weight, hipad_stream_t stream);
+int hipad_depth_loss_backward(float *grad_feat, const float *pred, const float *coef, const float *upstream,
+                              const unsigned short *feat, long long pyramid_rows, const hipad_depth_level *levels,
+                              int nlevels, int bs, int cams, float max_depth, hipad_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Image leg of the training data pipeline (hip-ad_amd/csrc/imgpipe.hip).  Replaces, for all camera images of one
  * sample and with the frames already in HBM as uint8 (n_img, src_h, src_w, 3):
  *   datasets/pipelines/augment.py:46-68      ResizeCropFlipImage._img_transform (PIL resize [bicubic] -> crop ->

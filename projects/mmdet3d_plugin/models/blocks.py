@@ -184,7 +184,21 @@ class DenseDepthNet(BaseModule):
             return self.loss(depths, gt_depths)
         return depths
 
+    def on_pyramid(self, flat, blocks, num_cams, levels, focal=None):
+        """The training-time handle of the fused path (hipad_amd/csrc/depthloss.hip): nothing is computed until
+        ``loss(handle, gt_depths)``, which reads the rows of the frame's flat bf16 pyramid ``flat`` (bs, rows, 256) in
+        place -- ``blocks[l]`` = (first row, rows per sample) of level ``l`` -- and adds the feature gradient into the
+        frame's shared pyramid-gradient buffer.  Iterating the handle evaluates the heads the module way."""
+        return PyramidDepth(self, flat, blocks, num_cams, levels, focal)
+
     def loss(self, depth_preds, gt_depths):
+        if isinstance(depth_preds, PyramidDepth):
+            h = depth_preds
+            n = min(self.num_depth_layers, len(gt_depths))
+            geometry = [(h.blocks[l][1] // h.num_cams, h.blocks[l][0]) for l in range(n)]
+            return HF.depth_loss(h.flat, h.focal, list(gt_depths[:n]), [m.weight for m in self.depth_layers[:n]],
+                                 [m.bias for m in self.depth_layers[:n]], geometry, h.num_cams, self.equal_focal,
+                                 self.max_depth, self.loss_weight)
         total = 0.0
         for pred, gt in zip(depth_preds, gt_depths):
             pred = pred.permute(0, 2, 3, 1).reshape(-1)
@@ -197,6 +211,16 @@ class DenseDepthNet(BaseModule):
             count = torch.clamp(valid.sum().float() * len(depth_preds), min=1.0)
             total = total + err / count * self.loss_weight
         return total
+
+
+class PyramidDepth:
+    """What DenseDepthNet.on_pyramid returns (see there)."""
+
+    def __init__(self, net, flat, blocks, num_cams, levels, focal):
+        self.net, self.flat, self.blocks, self.num_cams, self.levels, self.focal = net, flat, blocks, num_cams, levels, focal
+
+    def __iter__(self):
+        return iter(self.net(self.levels, self.focal))
 
 
 @FEEDFORWARD_NETWORK.register_module()

@@ -26,6 +26,7 @@ import os as _os
 
 FLAT_BF16 = _os.environ.get("HIPAD_FLAT_BF16", "1") == "1"   # 0: widen the flat pyramid to fp32 (round-1 behaviour)
 IN_PLACE_PYRAMID = _os.environ.get("HIPAD_IN_PLACE_PYRAMID", "1") == "1"   # 0: copy the levels into the camera-major layout
+FUSED_DEPTH = _os.environ.get("HIPAD_FUSED_DEPTH", "1") == "1"   # 0: depth heads as library convolutions + torch loss ops
 
 
 @DETECTORS.register_module()
@@ -99,8 +100,12 @@ class SparseDetector(BaseModule):
             levels = [f.view_as(f) for f in levels]
 
         depths = None
-        if return_depth and self.depth_branch is not None:
-            depths = self.depth_branch(levels, None if metas is None else metas.get("focal"))
+        focal = None if metas is None else metas.get("focal")
+        fused_depth = (return_depth and self.depth_branch is not None and in_place and FUSED_DEPTH and torch.is_grad_enabled()
+                       and hasattr(self.depth_branch, "on_pyramid")
+                       and all(m.weight.dtype == torch.float32 and m.bias is not None for m in self.depth_branch.depth_layers))
+        if return_depth and self.depth_branch is not None and not fused_depth:
+            depths = self.depth_branch(levels, focal)
         # the flat pyramid keeps the encoder's dtype: bf16 rows go to the aggregation kernels as they are (same values as
         # the reference's fp32 copy of its fp16 pyramid would hold, half the bytes); other widths / dtypes are widened
         if in_place:
@@ -109,6 +114,10 @@ class SparseDetector(BaseModule):
             keep = levels[0].dtype == torch.bfloat16 and levels[0].is_cuda and levels[0].shape[2] == 256 and FLAT_BF16
             feature_maps = feature_maps_format(levels, out_dtype=None if keep else torch.float32)
         feature_maps[0] = shared_feature_grad(feature_maps[0])
+        if fused_depth:
+            # the depth heads and their loss read the flat pyramid's rows in place and add their feature gradient into the
+            # shared buffer of the aggregation calls (evaluated when the loss is asked for)
+            depths = self.depth_branch.on_pyramid(feature_maps[0], tables[3], num_cams, levels, focal)
         # cut point of the eager step's two-part backward (hipad_amd.frame.TrainStep); rides on the flat tensor so that it
         # lives exactly as long as the forward's outputs (a persistent reference on the module kills ROCm 7.2's
         # capture_end when the step is captured)
