@@ -143,6 +143,10 @@ class TrainStep:
             self.grads.set_split(late[0])
         self._early_params = early
         self._loosened = False
+        # ids of parameters whose gradients OUR kernels write in place are collected during this step's first backward;
+        # ids left from an earlier model (tests build many) could be reused by Python for this model's parameters
+        from . import functional as _HF
+        _HF.INPLACE_PARAMS.clear()
         self._comm_stream = None
 
     @property

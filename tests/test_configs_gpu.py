@@ -137,10 +137,11 @@ def test_config4_stage2_bs2():
                     scale = ref.abs().max().clamp_min(1e-9)
                     err = float((t[b] - ref).abs().max() / scale)
                     # fp32 encoder, bf16-operand decoder: the fp32 convolutions of 12 and of 6 images differ in the last
-                    # bits, the decoder's operand rounding turns that into <= 1.6e-3 by the last layer (measured); a
-                    # sample reading another sample's rows is an O(1) error on EVERY instance
+                    # bits (the library picks its solvers per shape and per run), the decoder's operand rounding turns
+                    # that into 1.6e-3 .. 5.6e-3 by the last layer (measured over the round's runs); a sample reading
+                    # another sample's rows is an O(1) error on EVERY instance
                     if ti != 4:
-                        assert err < 5e-3, (ti, key, li, b, err)
+                        assert err < 1.5e-2, (ti, key, li, b, err)
                     else:
                         # the motion head's queries are the mode anchors of each box's ARG-MAX class turned by its yaw and
                         # passed through sin / cos of metres x 10000^(i/128): last-bit noise flips the class of a few
