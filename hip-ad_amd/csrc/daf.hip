@@ -532,7 +532,7 @@ using namespace hipad;
 
 extern "C" {
 
-int hipad_abi_version(void) { return 1; }
+int hipad_abi_version(void) { return 3; }  // 3: round-3 entry points (merged feature-gradient pass, fused objective, depth loss, glue)
 
 const char *hipad_status_string(int s) {
   switch (s) {

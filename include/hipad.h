@@ -31,7 +31,7 @@ extern "C" {
 
 typedef void *hipad_stream_t;
 
-/* ABI version (bumped on any signature change) and a static description string. */
+/* ABI version (bumped on any signature change or added entry point; 3 = this header) and a static description string. */
 int hipad_abi_version(void);
 const char *hipad_status_string(int status);
 
