@@ -304,6 +304,9 @@ __global__ __launch_bounds__(1024) void daf_alloc_kernel(int *__restrict__ cnt,
 // consecutive 64-tap batches one wave walks with its row sum carried along (hipad_daf_set_feat_run overrides)
 static int g_feat_run = 4;
 void daf_set_feat_run(int batches) { g_feat_run = batches > 0 && batches <= 64 ? batches : 4; }
+// most workgroups the accumulation pass is launched with (a persistent grid: waves take runs round-robin)
+static int g_feat_blocks = 2048;
+void daf_set_feat_blocks(int blocks) { g_feat_blocks = blocks >= 64 && blocks <= 65536 ? blocks : 2048; }
 
 __global__ __launch_bounds__(256) void daf_bwd_feat_kernel(
     float *__restrict__ gfeat, const int *__restrict__ taps, const int *__restrict__ offs,
@@ -676,7 +679,7 @@ static int run_sorted(const MultiArgs &m, const int *ss, const int *start, float
   const long long tmax = (long long)npair * L * 4;
   const int kFeatRun = g_feat_run;
   long long nb = (tmax + 256 * kFeatRun - 1) / (256 * kFeatRun);
-  if (nb > 2048) nb = 2048;
+  if (nb > g_feat_blocks) nb = g_feat_blocks;
   hipLaunchKernelGGL(daf_bwd_feat_kernel, dim3((unsigned)nb), dim3(256), 0, stream, gfeat, (const int *)w.taps,
                      (const int *)w.offs, (const int *)w.cursor, (const int *)(w.cnt + R), m, ss, start, R, cams, num_feat,
                      L, npair * L, kFeatRun);
@@ -722,6 +725,7 @@ extern "C" {
 
 void hipad_daf_set_tap_chunks(int chunks) { hipad::daf_set_tap_chunks(chunks); }
 void hipad_daf_set_feat_run(int batches) { hipad::daf_set_feat_run(batches); }
+void hipad_daf_set_feat_blocks(int blocks) { hipad::daf_set_feat_blocks(blocks); }
 
 size_t hipad_daf_backward_feat_multi_workspace(const hipad_daf_call *calls, int ncalls, int bs, int cams, int num_feat,
                                                int C, int L, int G) {

@@ -27,6 +27,7 @@ SIGNATURES = {
     "hipad_daf_taps": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
     "hipad_daf_set_tap_chunks": (None, [c_int]),
     "hipad_daf_set_feat_run": (None, [c_int]),
+    "hipad_daf_set_feat_blocks": (None, [c_int]),
     "hipad_weights_softmax_set_split": (None, [c_int]),
     "hipad_daf_backward_feat_multi_workspace": (c_size_t, [c_void_p, c_int] + [c_int] * 6),
     "hipad_daf_backward_feat_multi": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 6

@@ -25,6 +25,13 @@ def timed():
     return e0.elapsed_time(e1) / 20 * 1e3
 
 
+blocks = [int(v[7:]) for v in sys.argv[1:] if v.startswith("blocks=")]
+for b in blocks:
+    lib.hipad_daf_set_feat_blocks(b)
+    print("blocks %5d: %.1f us per frame pass" % (b, timed()), flush=True)
+if blocks:
+    lib.hipad_daf_set_feat_blocks(0)
+    sys.exit(0)
 runs = [int(v[4:]) for v in sys.argv[1:] if v.startswith("run=")]
 for r in runs:
     lib.hipad_daf_set_feat_run(r)
