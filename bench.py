@@ -378,8 +378,12 @@ def pmc_traffic(kernel, A, P):
         table = json.load(f)["kernels"]
     if kernel == "frame_pass":            # the frame's merged pass: every kernel of it, each launched once per pass
         parts = [v for k, v in table.items()
-                 if k.startswith(("hipad::daf_bwd_feat_kernel grid=524288", "hipad::daf_tap_pass_kernel", "hipad::daf_alloc_kernel",
-                                  "hipad::fill_zero_kernel"))]
+                 if k.startswith(("hipad::daf_tap_pass_kernel", "hipad::daf_alloc_kernel", "hipad::fill_zero_kernel"))]
+        # the accumulation kernel of the frame pass = its launch with the largest grid (single-call pipelines launch fewer
+        # workgroups; tools/pmc_daf_frame.py runs only the frame pass)
+        feat = [(int(k.rsplit("=", 1)[1]), v) for k, v in table.items() if k.startswith("hipad::daf_bwd_feat_kernel grid=")]
+        if feat:
+            parts.append(max(feat, key=lambda kv: kv[0])[1])
         return sum(v["hbm_bytes_per_launch"] for v in parts) if parts else None
     else:
         hit = table.get("hipad::%s grid=%d" % (kernel, _daf_grid_threads(A, P)))

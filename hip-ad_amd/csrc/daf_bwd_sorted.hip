@@ -304,9 +304,11 @@ __global__ __launch_bounds__(1024) void daf_alloc_kernel(int *__restrict__ cnt,
 // consecutive 64-tap batches one wave walks with its row sum carried along (hipad_daf_set_feat_run overrides)
 static int g_feat_run = 4;
 void daf_set_feat_run(int batches) { g_feat_run = batches > 0 && batches <= 64 ? batches : 4; }
-// most workgroups the accumulation pass is launched with (a persistent grid: waves take runs round-robin)
-static int g_feat_blocks = 2048;
-void daf_set_feat_blocks(int blocks) { g_feat_blocks = blocks >= 64 && blocks <= 65536 ? blocks : 2048; }
+// most workgroups the accumulation pass is launched with (waves take runs round-robin).  Frame pass on MI355X
+// (tools/sweep_tap_chunks.py blocks=...): 1024 545 us, 2048 514, 4096 499, 8192 497, 16384 498 -- with about one run
+// per wave nobody waits for a wave that drew one run more
+static int g_feat_blocks = 8192;
+void daf_set_feat_blocks(int blocks) { g_feat_blocks = blocks >= 64 && blocks <= 65536 ? blocks : 8192; }
 
 __global__ __launch_bounds__(256) void daf_bwd_feat_kernel(
     float *__restrict__ gfeat, const int *__restrict__ taps, const int *__restrict__ offs,
@@ -675,7 +677,7 @@ static int run_sorted(const MultiArgs &m, const int *ss, const int *start, float
                      w.cursor, R);
   hipLaunchKernelGGL(daf_tap_pass_kernel<true>, pg, pb, 0, stream, w.cursor, w.taps, ss, start, m, npair, cams,
                      num_feat, L, cap, nch);
-  // persistent grid: up to 2048 blocks x 4 waves walk the batches of 64 taps
+  // grid: up to g_feat_blocks workgroups x 4 waves, each wave walks runs of g_feat_run batches of 64 taps
   const long long tmax = (long long)npair * L * 4;
   const int kFeatRun = g_feat_run;
   long long nb = (tmax + 256 * kFeatRun - 1) / (256 * kFeatRun);

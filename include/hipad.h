@@ -152,7 +152,7 @@ void hipad_daf_set_tap_chunks(int chunks);
 /* Tuning knob of the accumulation pass: consecutive batches of 64 sorted taps one wave walks with its row sum carried
  * along (rows inside a run are written without atomics); 1..64, anything else = the default (4). */
 void hipad_daf_set_feat_run(int batches);
-/* ... and the most workgroups of that pass's persistent grid; 64..65536, anything else = the default (2048). */
+/* ... and the most workgroups of that pass's persistent grid; 64..65536, anything else = the default (8192). */
 void hipad_daf_set_feat_blocks(int blocks);
 
 size_t hipad_daf_backward_feat_multi_workspace(const hipad_daf_call *calls, int ncalls, int batch_size, int num_cams,
