@@ -363,8 +363,10 @@ def test_feat_multi_is_the_same_for_every_run_length(lib, run):
     gf = torch.zeros(feat.shape, device="cuda")
     try:
         lib.load().hipad_daf_set_feat_run(run)
+        lib.load().hipad_daf_set_feat_blocks(64 if run % 2 else 0)      # a small grid: every wave walks several runs
         lib.daf_backward_feat_multi([tuple(t.cuda() for t in c) for c in calls], gf, torch.from_numpy(ss).cuda(),
                                     torch.from_numpy(st).cuda())
     finally:
         lib.load().hipad_daf_set_feat_run(0)
+        lib.load().hipad_daf_set_feat_blocks(0)
     assert rel_err(gf, ref) < 1e-5
